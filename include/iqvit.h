@@ -1,0 +1,191 @@
+/* iqvit.h -- C ABI of the MI355X-native (gfx950) training path for the ViT / raw-IQ
+ * modulation classifiers of aliftffd/ViT-vs-Raw-IQ.
+ *
+ * The reference has no FFI layer: its boundary is the Python nn.Module surface
+ * (SURVEY.md section 8b).  This header is the boundary the MI355X build puts underneath
+ * that surface: plain pointers and sizes, no torch types.  Every pointer is DEVICE memory
+ * (HBM) unless marked host.  All activations are bf16 (uint16 storage), row-major,
+ * tokens-major [B*S, D]; parameters, gradients, statistics, logits and losses are fp32.
+ * Every launch goes to the hipStream_t passed as `stream` (iq_stream_t == hipStream_t);
+ * no call synchronises, allocates or frees, so a call sequence can be captured in a hipGraph.
+ * Return value: 0 ok; IQ_ERR_* otherwise (host mirrors map them to Python exceptions).
+ *
+ * Citations are to /root/reference/Transformer_Thesis/ (V/ = ViT/, R/ = transformer_rawIQ/).
+ */
+#ifndef IQVIT_H
+#define IQVIT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* iq_stream_t; /* hipStream_t */
+
+enum { IQ_STATUS_OK = 0, IQ_STATUS_ARG = 1, IQ_STATUS_UNSUPPORTED = 2, IQ_STATUS_LAUNCH = 3 };
+
+/* Dropout site: Philox4x32-10 keyed by seed, counter (element_index/8, site, step).
+ * p == 0 disables.  Masks are regenerated in backward from the same triple, never stored. */
+typedef struct iq_dropout {
+  uint64_t seed;
+  uint32_t step;
+  uint32_t site;
+  float p;
+  const uint32_t* step_dev; /* optional DEVICE u32 overriding `step` (bumped on device under hipGraph replay) */
+} iq_dropout_t;
+
+/* ---------------------------------------------------------------------------------------
+ * LayerNorm.  Replaces LayerNorm.forward, V/models/layers/layers_norm.py:11-19 (eps 1e-12,
+ * biased variance) and its autograd backward; also nn.LayerNorm (eps 1e-5) of the rawIQ head.
+ * z,x,dx,dz,dy: bf16 [M,D]; gamma,beta,dgamma,dbeta: fp32 [D]; mean,rstd: fp32 [M].
+ * iq_ln_bwd optionally emits dy = dropout(dz) for the site that preceded the residual add
+ * (V/models/blocks/encoder_layer.py:24-25,32-33).  ws: iq_ln_bwd_ws_bytes(D) scratch. */
+int iq_ln_supported(int D);
+int iq_ln_fwd(const void* z, const float* gamma, const float* beta, void* x, float* mean, float* rstd, int M, int D,
+              float eps, iq_stream_t stream);
+size_t iq_ln_bwd_ws_bytes(int D);
+int iq_ln_bwd(const void* dx, const void* z, const float* mean, const float* rstd, const float* gamma, void* dz,
+              void* dy, const iq_dropout_t* drop, float* dgamma, float* dbeta, float* ws, int accumulate, int M,
+              int D, iq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * bf16 MFMA GEMM, C[M,N] = epilogue(A[M,K] * B[N,K]^T), fp32 accumulate.
+ * Replaces every nn.Linear on the path: w_q/w_k/w_v/w_concat
+ * (V/models/layers/multi_head_attention.py:18,28), linear1/linear2
+ * (V/models/layers/position_wise_feed_forward.py:13-16), the non-overlapping Conv2d/Conv1d
+ * of the embeddings (V/models/embedding/patch_embedding.py:9-15,
+ * R/models/embedding/patch_embedding.py:29-43) and, with B = W^T shadows, their dgrads.
+ * Epilogue order: +bias, relu, +pe (row remap), dropout, *gate, +residual.
+ *   tok>0 : embedding mode, output row = (m/tok)*seq + m%tok + cls_off and pe[(m%tok+cls_off),:]
+ *           is added (V/models/encoder.py:42-47).
+ *   gate  : v *= (gate[m,n] > 0) ? gate_scale : 0   (ReLU+dropout backward from the saved hidden).
+ * K%8==0, N%8==0, lda/ldb/ldc/ldr/ldg in elements and %8==0. */
+typedef struct iq_epilogue {
+  const float* bias;    /* [N] or NULL */
+  int relu;
+  const float* pe;      /* [seq, N] fp32 or NULL (embedding mode) */
+  int tok, seq, cls_off;
+  iq_dropout_t drop;    /* indexed by OUTPUT element (row_out*N + n) */
+  const void* gate;     /* bf16 [M, ldg] or NULL */
+  int ldg;
+  float gate_scale;
+  const void* residual; /* bf16 [M_out, ldr] or NULL */
+  int ldr;
+} iq_epilogue_t;
+int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                    const iq_epilogue_t* epi, iq_stream_t stream);
+
+/* Weight gradient: dW[N,K] (+)= dY[M,N]^T * X[M,K]; dbias[N] (+)= colsum(dY) (NULL to skip).
+ * Split over M into slabs in `ws` (iq_wgrad_ws_bytes), reduced deterministically (no atomics). */
+size_t iq_wgrad_ws_bytes(int M, int N, int K);
+int iq_gemm_bf16_wgrad(const void* dY, int ldy, const void* X, int ldx, float* dW, float* dbias, int M, int N, int K,
+                       float* ws, size_t ws_bytes, int accumulate, iq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Scaled-dot-product attention core, softmax(Q K^T / sqrt(dh)) V per (frame, head), no mask,
+ * no dropout.  Replaces ScaleDotProductAttention.forward
+ * (V/models/layers/scale_dot_product_attention.py:23-39) plus MultiHeadAttention.split/concat
+ * (V/models/layers/multi_head_attention.py:34-47): reads the packed projection output
+ * qkv[B*S, 3*D] (q | k | v, head h at columns h*dh) and writes out[B*S, D] already "concatenated".
+ * The S x S scores never reach HBM; lse[B,H,S] (fp32, natural log) is kept for backward.
+ * dh in {16,32,64}. */
+int iq_attn_supported(int S, int dh);
+int iq_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int dh, iq_stream_t stream);
+int iq_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int S, int H,
+                int dh, iq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Embedding front end.  iq_patchify turns the fp32 input frame batch into the bf16 GEMM
+ * operand [B*tok, Kpad] (patch element order = the conv weight's (c, py, px) / (c, j) order,
+ * zero padded to Kpad); kind 0: src (B,C,H,W), patch p  (V/models/embedding/patch_embedding.py:11-15)
+ *               kind 1: src (B,C,L),   kernel = stride = k (R/models/embedding/patch_embedding.py:47-60).
+ * iq_cls_rows writes row 0 of every frame: dropout(cls + pe[0]) (V/models/encoder.py:42-47).
+ * iq_embed_bwd_gather compacts d(x0) rows (dropping cls rows, re-applying the dropout mask)
+ * into [B*tok, D] for the embedding wgrad and reduces d(cls) = sum_b d(x0)[b,0,:]. */
+int iq_patchify(const float* src, void* patches, int kind, int B, int C, int H, int W, int p, int Kpad,
+                iq_stream_t stream);
+int iq_cls_rows(const float* cls, const float* pe, void* x0, int B, int S, int D, const iq_dropout_t* drop,
+                iq_stream_t stream);
+int iq_embed_bwd_gather(const void* dx0, void* demb, float* dcls, int B, int S, int tok, int D, int has_cls,
+                        const iq_dropout_t* drop, int accumulate, iq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Classification head + loss.
+ * iq_head_fwd: feat = x[:,0,:] (pool=0) or mean over tokens (pool=1); optional LayerNorm (eps 1e-5,
+ * R/models/transformer_rawIQ.py:67-70,88-96); logits = feat*W^T + b (V/models/amc_transformer.py:29-30).
+ * featn [B,D] fp32 (the pooled feature, normalised but pre-affine when LN is on) and hstat [B,2]
+ * (mean, rstd) are kept for backward.
+ * iq_ce_fwd_bwd: CrossEntropyLoss(label_smoothing) mean over `denom` frames (global batch under DDP),
+ * V/training/train.py:405; writes loss_sum (sum over local frames of per-frame loss), n_correct
+ * (argmax==label, V/training/train.py:205-207) and dlogits.  Pass dlogits NULL to skip the gradient.
+ * iq_head_bwd: gradients of W,b,(ln gamma,beta) and d(x_L) (bf16 [B*S,D], zero outside the pooled rows). */
+int iq_head_fwd(const void* x, const float* ln_g, const float* ln_b, const float* W, const float* b, float* featn,
+                float* hstat, float* logits, int B, int S, int D, int K, int pool, iq_stream_t stream);
+int iq_ce_fwd_bwd(const float* logits, const int64_t* labels, int B, int K, float smoothing, float denom,
+                  float* loss_sum, int32_t* n_correct, float* dlogits, iq_stream_t stream);
+int iq_head_bwd(const float* dlogits, const float* featn, const float* hstat, const float* ln_g, const float* ln_b,
+                const float* W, float* dW, float* db, float* dln_g, float* dln_b, void* dx, int B, int S, int D, int K,
+                int pool, int accumulate, iq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Optimizer on the flat fp32 parameter / gradient buffers.
+ * iq_gradnorm_sq: out[0] = sum(g^2)  (clip_grad_norm_, V/training/train.py:199).
+ * iq_adamw_step: clip scale min(1, max_norm/(sqrt(gnorm_sq)+1e-6)) folded into AdamW with decoupled
+ * weight decay on every element (V/training/train.py:407-412); also writes the bf16 shadow.
+ * max_norm <= 0 or gnorm_sq NULL disables clipping.  grad_scale multiplies g first (1/world_size). */
+size_t iq_gradnorm_ws_bytes(size_t n);
+int iq_gradnorm_sq(const float* g, size_t n, float grad_scale, float* ws, float* out, iq_stream_t stream);
+int iq_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, size_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, const float* gnorm_sq, float max_norm,
+                  float grad_scale, const float* dyn, iq_stream_t stream);
+/* dyn: optional DEVICE float[2] = {lr, step}; when non-NULL it overrides lr/step (graph replay).
+ * iq_counter_add: *ctr_u32 += inc_u32 and/or *ctr_f32 += inc_f32 (either pointer may be NULL). */
+int iq_counter_add(uint32_t* ctr_u32, uint32_t inc_u32, float* ctr_f32, float inc_f32, iq_stream_t stream);
+int iq_cast_bf16(const float* src, void* dst, size_t n, iq_stream_t stream);
+/* dst[c, r] (ld = rows_pad) = bf16(src[r, c]); src fp32 [rows, cols] */
+int iq_transpose_cast_bf16(const float* src, void* dst, int rows, int cols, iq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Whole-model plan: the native runtime underneath AMCTransformer.forward / loss.backward().
+ * Mirrors the constructors V/models/amc_transformer.py:9 and R/models/transformer_rawIQ.py:14-26. */
+typedef struct iq_model_cfg {
+  int kind;            /* 0 = ViT (2-D patches), 1 = raw-IQ (1-D sequence) */
+  int in_channels;
+  int img_h, img_w, patch;            /* kind 0 */
+  int seq_length, conv_k, use_cls;    /* kind 1: conv_k = segment_size, or 1 for embedding_type 'conv1d' */
+  int num_classes, d_model, n_head, n_layers, ffn_hidden;
+  float drop_prob;
+} iq_model_cfg_t;
+
+typedef struct iq_model iq_model_t;
+
+int iq_model_create(const iq_model_cfg_t* cfg, iq_model_t** out);
+void iq_model_destroy(iq_model_t* m);
+const char* iq_model_last_error(const iq_model_t* m);
+int iq_model_tokens(const iq_model_t* m);   /* S, cls included */
+/* flat fp32 parameter buffer layout: entries in reference state_dict naming */
+size_t iq_model_param_floats(const iq_model_t* m);
+int iq_model_param_entries(const iq_model_t* m);
+int iq_model_param_entry(const iq_model_t* m, int i, char* name, int name_cap, size_t* offset, int* ndim, int* dims);
+size_t iq_model_shadow_bytes(const iq_model_t* m);
+size_t iq_model_workspace_bytes(const iq_model_t* m, int batch, int training);
+/* bind device buffers (caller-owned, must outlive use): params/grads flat fp32, pe fp32 [S,D], shadow bytes */
+int iq_model_bind(iq_model_t* m, float* params, float* grads, const float* pe, void* shadow);
+int iq_model_refresh_shadow(iq_model_t* m, iq_stream_t stream);
+/* forward: src fp32 (B,C,H,W)/(B,C,L); enc_out fp32 [B,S,D] or NULL; logits fp32 [B,K] or NULL */
+int iq_model_forward(iq_model_t* m, const float* src, int batch, void* workspace, size_t ws_bytes, int training,
+                     uint64_t seed, uint32_t step, float* enc_out, float* logits, iq_stream_t stream);
+/* backward of the last training forward in `workspace`: dlogits fp32 [B,K] and/or denc fp32 [B,S,D].
+ * Gradients are WRITTEN (accumulate=0) or added into the bound flat grad buffer.
+ * layer_hi/layer_lo select a slice of the chain for comm overlap: stage ids run
+ * n_layers+1 (head) ... 1 (layer 0) ... 0 (embedding); call with (n_layers+1, 0) for everything. */
+int iq_model_backward(iq_model_t* m, const float* dlogits, const float* denc, int batch, void* workspace,
+                      size_t ws_bytes, int accumulate, int stage_hi, int stage_lo, iq_stream_t stream);
+/* flat-gradient range [*off, *off+*len) written by stages [stage_lo, stage_hi] (DDP buckets) */
+int iq_model_grad_range(const iq_model_t* m, int stage_hi, int stage_lo, size_t* off, size_t* len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IQVIT_H */

@@ -1,0 +1,455 @@
+"""GPU (MI355X): every C-ABI op of include/iqvit.h against a plain PyTorch fp32/fp64 reference of the
+same op, called through ctypes exactly as the host layer calls it.  Inputs are rounded to bf16 first so
+the comparison isolates the kernel (fp32 accumulate, bf16 store) from input quantisation.
+
+Tolerances (stated, floating point): bf16 outputs  |err| <= 2^-7 * |ref| + small abs (one bf16 ulp is
+2^-8 relative);  fp32 outputs (statistics, weight gradients, losses) rtol 2e-3 of the tensor scale,
+which is the bf16-product / fp32-accumulate error at these contraction lengths.
+"""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import vit_vs_raw_iq_amd._native as N
+    return N.lib()
+
+
+def _N():
+    import vit_vs_raw_iq_amd._native as N
+    return N
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def close_bf16(got, ref, what="", rel=2 ** -7, abs_=None):
+    got = got.float()
+    ref = ref.float()
+    scale = ref.abs().max().item() + 1e-12
+    abs_ = abs_ if abs_ is not None else 4e-3 * scale
+    err = (got - ref).abs()
+    bad = err > (rel * ref.abs() + abs_)
+    assert not bad.any(), f"{what}: {int(bad.sum())} elements off, max err {err.max().item():.4g} (scale {scale:.4g})"
+
+
+def close_f32(got, ref, what="", rtol=2e-3):
+    scale = ref.abs().max().item() + 1e-12
+    err = (got.float() - ref.float()).abs().max().item()
+    assert err <= rtol * scale, f"{what}: max err {err:.4g} vs scale {scale:.4g}"
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D", [64, 128, 192, 256, 768, 32, 96])
+@pytest.mark.parametrize("M", [1, 37, 4100])
+def test_ln_fwd_bwd(L, D, M):
+    N = _N()
+    assert L.iq_ln_supported(D) == 1
+    g = torch.Generator(device="cuda").manual_seed(D * 1000 + M)
+    z = bf(torch.randn(M, D, device=dev(), generator=g) * 2 + 0.3)
+    gamma = torch.randn(D, device=dev(), generator=g)
+    beta = torch.randn(D, device=dev(), generator=g)
+    x = torch.empty_like(z)
+    mean = torch.empty(M, device=dev())
+    rstd = torch.empty(M, device=dev())
+    N.check(L.iq_ln_fwd(z.data_ptr(), gamma.data_ptr(), beta.data_ptr(), x.data_ptr(), mean.data_ptr(),
+                        rstd.data_ptr(), M, D, 1e-12, stream()), "ln_fwd")
+    zf = z.double()
+    mu = zf.mean(-1, keepdim=True)
+    var = zf.var(-1, unbiased=False, keepdim=True)
+    ref = gamma.double() * ((zf - mu) / torch.sqrt(var + 1e-12)) + beta.double()
+    close_bf16(x, ref, "ln out")
+    close_f32(mean, mu.squeeze(1), "mean", 1e-5)
+    close_f32(rstd, (1 / torch.sqrt(var + 1e-12)).squeeze(1), "rstd", 1e-4)
+
+    dx = bf(torch.randn(M, D, device=dev(), generator=g))
+    dz = torch.empty_like(z)
+    dgamma = torch.full((D,), 7.0, device=dev())
+    dbeta = torch.full((D,), -3.0, device=dev())
+    ws = torch.empty(L.iq_ln_bwd_ws_bytes(D), dtype=torch.uint8, device=dev())
+    N.check(L.iq_ln_bwd(dx.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                        dz.data_ptr(), None, None, dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), 0, M, D,
+                        stream()), "ln_bwd")
+    zr = z.double().requires_grad_(True)
+    gr = gamma.double().requires_grad_(True)
+    br = beta.double().requires_grad_(True)
+    mu = zr.mean(-1, keepdim=True)
+    var = zr.var(-1, unbiased=False, keepdim=True)
+    out = gr * ((zr - mu) / torch.sqrt(var + 1e-12)) + br
+    out.backward(dx.double())
+    close_bf16(dz, zr.grad, "ln dz")
+    close_f32(dgamma, gr.grad, "dgamma", 1e-3)
+    close_f32(dbeta, br.grad, "dbeta", 1e-3)
+    # accumulate=1 adds
+    N.check(L.iq_ln_bwd(dx.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                        dz.data_ptr(), None, None, dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), 1, M, D,
+                        stream()), "ln_bwd acc")
+    close_f32(dgamma, 2 * gr.grad, "dgamma acc", 1e-3)
+
+
+def test_ln_unsupported_width_is_refused(L):
+    assert L.iq_ln_supported(20) == 0
+    assert L.iq_ln_supported(136) == 0      # 17 vectors per row: not instantiated
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM NT + epilogues
+# ------------------------------------------------------------------------------------------------
+def run_gemm(L, A, B, M, N_, K, **kw):
+    N = _N()
+    Cout = torch.zeros(kw.pop("rows_out", M), N_, dtype=torch.bfloat16, device=dev())
+    e = N.Epilogue()
+    keep = []
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            keep.append(v)
+            setattr(e, k, v.data_ptr())
+        elif k == "drop":
+            e.drop = v
+        else:
+            setattr(e, k, v)
+    N.check(L.iq_gemm_bf16_nt(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), Cout.data_ptr(), N_, M, N_, K,
+                              C.byref(e), stream()), "gemm_nt")
+    torch.cuda.synchronize()
+    return Cout
+
+
+@pytest.mark.parametrize("M,N_,K", [(1, 64, 32), (130, 192, 192), (1000, 576, 192), (777, 768, 192), (300, 192, 768),
+                                    (513, 128, 1024), (257, 40, 72), (129, 384, 128), (2000, 1024, 256)])
+def test_gemm_plain_and_bias_relu(L, M, N_, K):
+    g = torch.Generator(device="cuda").manual_seed(M + N_ + K)
+    A = bf(torch.randn(M, K, device=dev(), generator=g))
+    B = bf(torch.randn(N_, K, device=dev(), generator=g) / math.sqrt(K))
+    bias = torch.randn(N_, device=dev(), generator=g)
+    ref = A.double() @ B.double().t()
+    close_bf16(run_gemm(L, A, B, M, N_, K), ref, "plain")
+    close_bf16(run_gemm(L, A, B, M, N_, K, bias=bias), ref + bias.double(), "bias")
+    close_bf16(run_gemm(L, A, B, M, N_, K, bias=bias, relu=1), torch.relu(ref + bias.double()), "bias+relu")
+
+
+def test_gemm_asymmetric_layout(L):
+    """A = I picks out B^T exactly: catches swapped fragment / C-layout maps (guide 3)."""
+    K = 64
+    A = bf(torch.eye(K, device=dev()))
+    B = bf(torch.arange(128 * K, device=dev()).reshape(128, K).float() % 251 - 125)
+    out = run_gemm(L, A, B, K, 128, K)
+    assert torch.equal(out.float(), B.float().t())
+
+
+def test_gemm_residual_gate_strided(L):
+    M, N_, K = 515, 192, 576
+    g = torch.Generator(device="cuda").manual_seed(5)
+    Abig = bf(torch.randn(M, K + 64, device=dev(), generator=g))
+    A = Abig[:, :K]                                     # lda > K
+    B = bf(torch.randn(N_, K, device=dev(), generator=g) / math.sqrt(K))
+    R = bf(torch.randn(M, N_, device=dev(), generator=g))
+    G = bf(torch.randn(M, N_, device=dev(), generator=g))
+    ref = A.double() @ B.double().t()
+    out = run_gemm(L, A, B, M, N_, K, residual=R, ldr=N_)
+    close_bf16(out, ref + R.double(), "residual")
+    out = run_gemm(L, A, B, M, N_, K, gate=G, ldg=N_, gate_scale=1.25, residual=R, ldr=N_)
+    close_bf16(out, torch.where(G.double() > 0, ref * 1.25, torch.zeros_like(ref)) + R.double(), "gate+residual")
+
+
+def test_gemm_embedding_row_remap_and_pe(L):
+    Bf, tok, S, D, K = 7, 9, 10, 64, 32
+    g = torch.Generator(device="cuda").manual_seed(9)
+    A = bf(torch.randn(Bf * tok, K, device=dev(), generator=g))
+    W = bf(torch.randn(D, K, device=dev(), generator=g))
+    bias = torch.randn(D, device=dev(), generator=g)
+    pe = torch.randn(S, D, device=dev(), generator=g)
+    out = run_gemm(L, A, W, Bf * tok, D, K, rows_out=Bf * S, bias=bias, pe=pe, tok=tok, seq=S, cls_off=1)
+    ref = (A.double() @ W.double().t() + bias.double()).view(Bf, tok, D) + pe[1:].double()
+    out = out.view(Bf, S, D)
+    close_bf16(out[:, 1:], ref, "embed rows")
+    assert torch.count_nonzero(out[:, 0]) == 0          # cls rows untouched
+
+
+def _drop(seed, step, site, p):
+    N = _N()
+    d = N.Dropout()
+    d.seed, d.step, d.site, d.p, d.step_dev = seed, step, site, p, None
+    return d
+
+
+def test_dropout_statistics_and_regeneration(L):
+    """Philox masks: keep rate, 1/(1-p) scaling, determinism, and the SAME mask regenerated by the LN backward."""
+    N = _N()
+    M, D = 2048, 192
+    A = bf(torch.ones(M, D, device=dev()))
+    I = bf(torch.eye(D, device=dev()))
+    p = 0.25
+    out = run_gemm(L, A, I, M, D, D, drop=_drop(123, 7, 4, p)).float()
+    keep = out != 0
+    assert abs(keep.float().mean().item() - (1 - p)) < 0.005
+    assert torch.allclose(out[keep], torch.full_like(out[keep], 1 / (1 - p)), rtol=1e-2)
+    out2 = run_gemm(L, A, I, M, D, D, drop=_drop(123, 7, 4, p)).float()
+    assert torch.equal(out, out2)
+    for other in (_drop(124, 7, 4, p), _drop(123, 8, 4, p), _drop(123, 7, 5, p)):
+        o = run_gemm(L, A, I, M, D, D, drop=other).float()
+        assert (o != 0).ne(keep).float().mean().item() > 0.2
+    # device-resident step overrides the host value
+    step_dev = torch.tensor([7], dtype=torch.int32, device=dev())
+    d = _drop(123, 99, 4, p)
+    d.step_dev = step_dev.data_ptr()
+    assert torch.equal(run_gemm(L, A, I, M, D, D, drop=d).float(), out)
+    # LN backward regenerates the identical mask for dy
+    z = bf(torch.randn(M, D, device=dev()))
+    gamma = torch.ones(D, device=dev())
+    beta = torch.zeros(D, device=dev())
+    x = torch.empty_like(z)
+    mean = torch.empty(M, device=dev())
+    rstd = torch.empty(M, device=dev())
+    N.check(L.iq_ln_fwd(z.data_ptr(), gamma.data_ptr(), beta.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                        M, D, 1e-12, stream()), "ln")
+    dx = bf(torch.randn(M, D, device=dev()) + 3)
+    dz, dy = torch.empty_like(z), torch.empty_like(z)
+    dg, db = torch.empty(D, device=dev()), torch.empty(D, device=dev())
+    ws = torch.empty(L.iq_ln_bwd_ws_bytes(D), dtype=torch.uint8, device=dev())
+    dr = _drop(123, 7, 4, p)
+    N.check(L.iq_ln_bwd(dx.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dz.data_ptr(),
+                        dy.data_ptr(), C.byref(dr), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), 0, M, D, stream()), "ln_bwd")
+    nz = dz.float() != 0
+    assert torch.equal((dy.float() != 0)[nz], keep[nz])
+    close_bf16(dy.float()[keep & nz], dz.float()[keep & nz] / (1 - p), "dy scale")
+
+
+# ------------------------------------------------------------------------------------------------
+# weight gradient
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N_,K", [(64, 128, 128), (1000, 192, 192), (5000, 768, 192), (3333, 192, 768),
+                                    (777, 576, 192), (130, 40, 72), (4096, 128, 32), (20000, 128, 1024)])
+def test_wgrad(L, M, N_, K):
+    N = _N()
+    g = torch.Generator(device="cuda").manual_seed(M + 3 * N_ + K)
+    dY = bf(torch.randn(M, N_, device=dev(), generator=g))
+    X = bf(torch.randn(M, K, device=dev(), generator=g))
+    dW = torch.full((N_, K), 5.0, device=dev())
+    db = torch.full((N_,), 5.0, device=dev())
+    nbytes = L.iq_wgrad_ws_bytes(M, N_, K)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+    N.check(L.iq_gemm_bf16_wgrad(dY.data_ptr(), N_, X.data_ptr(), K, dW.data_ptr(), db.data_ptr(), M, N_, K,
+                                 ws.data_ptr(), nbytes, 0, stream()), "wgrad")
+    ref = dY.double().t() @ X.double()
+    close_f32(dW, ref, "dW")
+    close_f32(db, dY.double().sum(0), "db")
+    N.check(L.iq_gemm_bf16_wgrad(dY.data_ptr(), N_, X.data_ptr(), K, dW.data_ptr(), db.data_ptr(), M, N_, K,
+                                 ws.data_ptr(), nbytes, 1, stream()), "wgrad acc")
+    close_f32(dW, 2 * ref, "dW acc")
+
+
+def test_wgrad_exact_integers(L):
+    """Small integers are exact in bf16 and fp32: the transposing LDS reads must reproduce dY^T X bit for bit."""
+    N = _N()
+    M, N_, K = 200, 128, 64
+    dY = bf((torch.arange(M * N_, device=dev()).reshape(M, N_) % 7 - 3).float())
+    X = bf((torch.arange(M * K, device=dev()).reshape(M, K) % 5 - 2).float())
+    dW = torch.empty(N_, K, device=dev())
+    nbytes = L.iq_wgrad_ws_bytes(M, N_, K)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+    N.check(L.iq_gemm_bf16_wgrad(dY.data_ptr(), N_, X.data_ptr(), K, dW.data_ptr(), None, M, N_, K, ws.data_ptr(),
+                                 nbytes, 0, stream()), "wgrad")
+    assert torch.equal(dW, (dY.double().t() @ X.double()).float())
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def attn_ref(qkv, Bf, S, H, dh):
+    D = H * dh
+    q, k, v = [t.view(Bf, S, H, dh).transpose(1, 2) for t in qkv.view(Bf, S, 3, D).unbind(2)]
+    s = (q @ k.transpose(2, 3)) / math.sqrt(dh)
+    p = torch.softmax(s, dim=-1)
+    o = (p @ v).transpose(1, 2).reshape(Bf * S, D)
+    return o, torch.logsumexp(s, dim=-1)
+
+
+@pytest.mark.parametrize("S,H,dh,Bf", [(5, 8, 16, 3), (17, 2, 32, 2), (65, 8, 16, 4), (129, 8, 16, 2), (65, 8, 32, 2),
+                                       (197, 3, 64, 3), (33, 2, 64, 2), (1025, 8, 16, 1), (224, 1, 64, 1)])
+def test_attention_fwd_bwd(L, S, H, dh, Bf):
+    N = _N()
+    assert L.iq_attn_supported(S, dh) == 1
+    D = H * dh
+    g = torch.Generator(device="cuda").manual_seed(S * 100 + dh)
+    qkv = bf(torch.randn(Bf * S, 3 * D, device=dev(), generator=g))
+    out = torch.empty(Bf * S, D, dtype=torch.bfloat16, device=dev())
+    lse = torch.empty(Bf, H, S, device=dev())
+    N.check(L.iq_attn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), Bf, S, H, dh, stream()), "attn_fwd")
+    qr = qkv.double().requires_grad_(True)
+    oref, lref = attn_ref(qr, Bf, S, H, dh)
+    close_bf16(out, oref.detach(), "attn out", rel=2 ** -6)
+    close_f32(lse, lref.detach(), "lse", 2e-3)
+    dout = bf(torch.randn(Bf * S, D, device=dev(), generator=g))
+    dqkv = torch.zeros_like(qkv)
+    N.check(L.iq_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), Bf, S, H,
+                          dh, stream()), "attn_bwd")
+    oref.backward(dout.double())
+    gref = qr.grad
+    scale = gref.abs().max().item()
+    err = (dqkv.double() - gref).abs()
+    # P and dS pass through bf16 before their MFMAs: allow 2% of the tensor scale
+    assert err.max().item() <= 0.02 * scale + 1e-6, f"attn bwd max err {err.max().item():.4g} scale {scale:.4g}"
+    rel_l2 = (err.pow(2).sum() / gref.pow(2).sum()).sqrt().item()
+    assert rel_l2 < 8e-3, rel_l2
+
+
+def test_attention_peaked_softmax_is_stable(L):
+    """Large logits: one key dominates each row (online max handling, no inf/nan)."""
+    N = _N()
+    Bf, S, H, dh = 2, 70, 2, 64
+    D = H * dh
+    g = torch.Generator(device="cuda").manual_seed(3)
+    qkv = bf(torch.randn(Bf * S, 3 * D, device=dev(), generator=g) * 6)
+    out = torch.empty(Bf * S, D, dtype=torch.bfloat16, device=dev())
+    lse = torch.empty(Bf, H, S, device=dev())
+    N.check(L.iq_attn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), Bf, S, H, dh, stream()), "attn_fwd")
+    oref, lref = attn_ref(qkv.double(), Bf, S, H, dh)
+    assert torch.isfinite(out.float()).all()
+    close_bf16(out, oref, "peaked", rel=2 ** -6, abs_=0.05)
+    close_f32(lse, lref, "lse", 2e-3)
+
+
+def test_attention_limits(L):
+    assert L.iq_attn_supported(197, 64) == 1
+    assert L.iq_attn_supported(1025, 16) == 1
+    assert L.iq_attn_supported(1025, 64) == 0   # backward images exceed LDS: documented limit
+    assert L.iq_attn_supported(64, 48) == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# embedding front end, head, loss, optimizer
+# ------------------------------------------------------------------------------------------------
+def test_patchify_matches_conv_unfold(L):
+    N = _N()
+    Bf, Cc, H, W, p = 3, 2, 16, 24, 4
+    x = torch.randn(Bf, Cc, H, W, device=dev())
+    P = Cc * p * p
+    Kpad = 32
+    out = torch.empty(Bf * (H // p) * (W // p), Kpad, dtype=torch.bfloat16, device=dev())
+    N.check(L.iq_patchify(x.data_ptr(), out.data_ptr(), 0, Bf, Cc, H, W, p, Kpad, stream()), "patchify")
+    ref = torch.nn.functional.unfold(x, kernel_size=p, stride=p).transpose(1, 2).reshape(-1, P)
+    assert torch.equal(out[:, :P], bf(ref))
+    assert Kpad == P or torch.count_nonzero(out[:, P:]) == 0
+    # 1-D
+    Lq, k = 64, 8
+    x1 = torch.randn(Bf, 2, Lq, device=dev())
+    out1 = torch.empty(Bf * (Lq // k), 32, dtype=torch.bfloat16, device=dev())
+    N.check(L.iq_patchify(x1.data_ptr(), out1.data_ptr(), 1, Bf, 2, Lq, 0, k, 32, stream()), "patchify1d")
+    ref1 = x1.view(Bf, 2, Lq // k, k).permute(0, 2, 1, 3).reshape(-1, 2 * k)
+    assert torch.equal(out1[:, :2 * k], bf(ref1))
+    assert torch.count_nonzero(out1[:, 2 * k:]) == 0
+
+
+@pytest.mark.parametrize("pool,with_ln", [(0, False), (0, True), (1, True)])
+def test_head_ce_fwd_bwd(L, pool, with_ln):
+    N = _N()
+    Bf, S, D, K = 37, 9, 192, 19
+    g = torch.Generator(device="cuda").manual_seed(11 + pool)
+    x = bf(torch.randn(Bf * S, D, device=dev(), generator=g))
+    W = torch.randn(K, D, device=dev(), generator=g) / math.sqrt(D)
+    b = torch.randn(K, device=dev(), generator=g)
+    lg = torch.randn(D, device=dev(), generator=g) if with_ln else None
+    lb = torch.randn(D, device=dev(), generator=g) if with_ln else None
+    y = torch.randint(0, K, (Bf,), device=dev(), generator=g)
+    feat = torch.empty(Bf, D, device=dev())
+    hstat = torch.empty(Bf, 2, device=dev())
+    logits = torch.empty(Bf, K, device=dev())
+    N.check(L.iq_head_fwd(x.data_ptr(), N.ptr(lg), N.ptr(lb), W.data_ptr(), b.data_ptr(), feat.data_ptr(),
+                          hstat.data_ptr(), logits.data_ptr(), Bf, S, D, K, pool, stream()), "head_fwd")
+    xr = x.double().view(Bf, S, D).requires_grad_(True)
+    Wr, br = W.double().requires_grad_(True), b.double().requires_grad_(True)
+    f = xr[:, 0] if pool == 0 else xr.mean(1)
+    if with_ln:
+        lgr, lbr = lg.double().requires_grad_(True), lb.double().requires_grad_(True)
+        f = torch.nn.functional.layer_norm(f, (D,), lgr, lbr, 1e-5)
+    ref_logits = f @ Wr.t() + br
+    close_f32(logits, ref_logits.detach(), "logits", 1e-4)
+    loss_ref = torch.nn.functional.cross_entropy(ref_logits, y, label_smoothing=0.1)
+    loss_ref.backward()
+    loss_sum = torch.zeros(1, device=dev())
+    ncorr = torch.zeros(1, dtype=torch.int32, device=dev())
+    dlogits = torch.empty(Bf, K, device=dev())
+    N.check(L.iq_ce_fwd_bwd(logits.data_ptr(), y.data_ptr(), Bf, K, 0.1, float(Bf), loss_sum.data_ptr(),
+                            ncorr.data_ptr(), dlogits.data_ptr(), stream()), "ce")
+    assert abs(loss_sum.item() / Bf - loss_ref.item()) < 1e-4
+    assert ncorr.item() == int((ref_logits.argmax(1) == y).sum())
+    dW, db = torch.empty_like(W), torch.empty_like(b)
+    dlg = torch.empty(D, device=dev()) if with_ln else None
+    dlb = torch.empty(D, device=dev()) if with_ln else None
+    dx = torch.empty_like(x)
+    N.check(L.iq_head_bwd(dlogits.data_ptr(), feat.data_ptr(), hstat.data_ptr(), N.ptr(lg), N.ptr(lb), W.data_ptr(),
+                          dW.data_ptr(), db.data_ptr(), N.ptr(dlg), N.ptr(dlb), dx.data_ptr(), Bf, S, D, K, pool, 0,
+                          stream()), "head_bwd")
+    close_f32(dW, Wr.grad, "dW", 1e-3)
+    close_f32(db, br.grad, "db", 1e-3)
+    close_bf16(dx.view(Bf, S, D), xr.grad, "dx")
+    if with_ln:
+        close_f32(dlg, lgr.grad, "dln_g", 1e-3)
+        close_f32(dlb, lbr.grad, "dln_b", 1e-3)
+
+
+def test_gradnorm_clip_adamw_match_torch(L):
+    N = _N()
+    n = 100_000
+    g = torch.Generator(device="cuda").manual_seed(2)
+    p0 = torch.randn(n, device=dev(), generator=g)
+    grad = torch.randn(n, device=dev(), generator=g) * 0.05
+    # torch reference: clip_grad_norm_(1.0) + AdamW(lr 1e-4, wd 1e-3, betas (.9,.99)), three steps
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pr], lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.99))
+    p = p0.clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    shadow = torch.empty(n, dtype=torch.bfloat16, device=dev())
+    ws = torch.empty(L.iq_gradnorm_ws_bytes(n), dtype=torch.uint8, device=dev())
+    gn = torch.empty(1, device=dev())
+    for step in (1, 2, 3):
+        gstep = grad * step
+        pr.grad = gstep.clone()
+        total = torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        N.check(L.iq_gradnorm_sq(gstep.data_ptr(), n, 1.0, ws.data_ptr(), gn.data_ptr(), stream()), "gradnorm")
+        assert abs(math.sqrt(gn.item()) - total.item()) < 1e-4 * total.item()
+        N.check(L.iq_adamw_step(p.data_ptr(), gstep.data_ptr(), m.data_ptr(), v.data_ptr(), shadow.data_ptr(), n, 1e-4,
+                                0.9, 0.99, 1e-8, 1e-3, step, gn.data_ptr(), 1.0, 1.0, None, stream()), "adamw")
+        assert torch.allclose(p, pr.data, atol=2e-7, rtol=1e-6), (p - pr.data).abs().max()
+        assert torch.equal(shadow, p.to(torch.bfloat16))
+    # dyn (device lr/step) path gives the same update as host scalars
+    p2, m2, v2 = p0.clone(), torch.zeros_like(p), torch.zeros_like(p)
+    p3, m3, v3 = p0.clone(), torch.zeros_like(p), torch.zeros_like(p)
+    dyn = torch.tensor([3e-4, 1.0], device=dev())
+    N.check(L.iq_adamw_step(p2.data_ptr(), grad.data_ptr(), m2.data_ptr(), v2.data_ptr(), None, n, 0.0, 0.9, 0.99, 1e-8,
+                            1e-3, 0, None, 0.0, 1.0, dyn.data_ptr(), stream()), "adamw dyn")
+    N.check(L.iq_adamw_step(p3.data_ptr(), grad.data_ptr(), m3.data_ptr(), v3.data_ptr(), None, n, 3e-4, 0.9, 0.99, 1e-8,
+                            1e-3, 1, None, 0.0, 1.0, None, stream()), "adamw host")
+    assert torch.equal(p2, p3)
+
+
+def test_cast_and_transpose(L):
+    N = _N()
+    src = torch.randn(300, 200, device=dev())
+    dst = torch.empty(200, 300, dtype=torch.bfloat16, device=dev())
+    N.check(L.iq_transpose_cast_bf16(src.data_ptr(), dst.data_ptr(), 300, 200, stream()), "transpose")
+    assert torch.equal(dst, bf(src.t().contiguous()))
+    flat = torch.randn(1000, device=dev())
+    out = torch.empty(1000, dtype=torch.bfloat16, device=dev())
+    N.check(L.iq_cast_bf16(flat.data_ptr(), out.data_ptr(), 1000, stream()), "cast")
+    assert torch.equal(out, bf(flat))

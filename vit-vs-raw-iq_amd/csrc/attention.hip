@@ -1,0 +1,492 @@
+// Scaled-dot-product attention core, forward and backward, for gfx950 (MI355X).
+//
+// Reference: ScaleDotProductAttention.forward, V/models/layers/scale_dot_product_attention.py:23-39
+//   score = q k^T / sqrt(dh); softmax(-1); score @ v            (mask never used by any caller)
+// and MultiHeadAttention.split/concat, V/models/layers/multi_head_attention.py:34-47, which this
+// kernel folds into its addressing: it reads the packed projection output qkv[B*S, 3D]
+// (q | k | v, head h at columns h*dh) and writes out[B*S, D] already concatenated.
+// Backward is the autograd backward of the same (the reference materialises and saves the S x S
+// probabilities, 0.47 MB/layer/frame at S=197; here they never leave the chip: backward recomputes
+// them from Q, K and the saved log-sum-exp).
+//
+// One workgroup (4 waves) per (frame, head).  All products are mfma_f32_16x16x32_bf16 and are
+// oriented so that every accumulator tile is DIRECTLY the B operand of the product that consumes
+// it (guide 3, "an accumulator tile as the next MFMA's operand"):
+//   forward / backward phase B ("query on the lane"):
+//        S^T[key,q] = K Q^T ;  P^T -> B operand of  O^T[d,q] = V^T P^T   (and dQ^T = K^T dS^T)
+//   backward phase A ("key on the lane"):
+//        S[q,key] = Q K^T ;   P, dS -> B operands of dV^T[d,key] = dO^T P and dK^T = Q^T dS
+// The only transposed operands (V^T, K^T, dO^T, Q^T) come from row-major LDS images through
+// ds_read_b64_tr_b16.  K-slot order inside an MFMA is free as long as A and B agree: lane group g
+// uses rows {4g..4g+3} U {16+4g..16+4g+3} of each 32-row step, which is what two stacked 16x16
+// accumulator tiles hold and what tr_frag() fetches.
+// LDS images are [rows][dh+16] bf16 (32 B pad: conflict-free transposed reads, 2-way on row reads).
+// Softmax statistics fp32, exp2 domain.  dh in {16,32,64}; dh=16 zero-pads the QK^T contraction.
+#include "common.h"
+#include "iqvit.h"
+
+namespace {
+
+constexpr int ATT_THREADS = 256;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float NEG_BIG = -1.0e30f;
+
+template <int DH> struct AttCfg {
+  static constexpr int LD = (DH == 16) ? 16 : DH + 16;  // LDS row stride (elements)
+  static constexpr int KS = (DH + 31) / 32;              // 32-deep contraction steps over d
+  static constexpr int DT = DH / 16;                     // 16-wide d tiles
+  static constexpr int CPR = DH / 8;                     // 16 B chunks per row
+};
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int ld, int r0, int c0, int lane) {
+  const int i16 = lane & 15, g = lane >> 4;
+  const bf16* a = tile + (r0 + 4 * g + (i16 >> 2)) * ld + c0 + 4 * (i16 & 3);
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 16 * ld));
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// row-major fragment: 8 consecutive d of row `row`, contraction step s (d0 = 32 s + 8 g)
+template <int DH>
+__device__ __forceinline__ bf16x8 row_frag_lds(const bf16* tile, int row, int s, int lane) {
+  const int d0 = s * 32 + 8 * (lane >> 4);
+  bf16x8 v = {};
+  if (DH >= 32 || d0 < DH) v = *reinterpret_cast<const bf16x8*>(tile + row * AttCfg<DH>::LD + d0);
+  return v;
+}
+template <int DH>
+__device__ __forceinline__ bf16x8 row_frag_gmem(const bf16* base, long ldg, int row, int nrows, int s, int lane) {
+  const int d0 = s * 32 + 8 * (lane >> 4);
+  bf16x8 v = {};
+  if (row < nrows && (DH >= 32 || d0 < DH)) v = *reinterpret_cast<const bf16x8*>(base + (long)row * ldg + d0);
+  return v;
+}
+
+// stage rows [r_begin, r_begin+nrows_pad) of a [S, dh] head slice (global row stride ldg) into an LDS image,
+// zero-filling rows >= S
+template <int DH>
+__device__ __forceinline__ void stage_rows(bf16* img, const bf16* base, long ldg, int r_begin, int nrows_pad, int S,
+                                           int tid) {
+  constexpr int CPR = AttCfg<DH>::CPR, LD = AttCfg<DH>::LD;
+  for (int id = tid; id < nrows_pad * CPR; id += ATT_THREADS) {
+    const int r = id / CPR, c = id % CPR;
+    bf16x8 v = {};
+    if (r_begin + r < S) v = *reinterpret_cast<const bf16x8*>(base + (long)(r_begin + r) * ldg + c * 8);
+    *reinterpret_cast<bf16x8*>(img + r * LD + c * 8) = v;
+  }
+}
+
+__device__ __forceinline__ bf16x8 pack_b(const f32x4& lo, const f32x4& hi) {
+  bf16x8 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { v[r] = (bf16)lo[r]; v[4 + r] = (bf16)hi[r]; }
+  return v;
+}
+
+__device__ __forceinline__ float group4_max(float v) {  // across lane groups (lanes l, l^16, l^32, l^48)
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group4_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                               float* __restrict__ lse, int S, int H, int kchunk,
+                                                               float scale_log2) {
+  using C = AttCfg<DH>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16* Ks = reinterpret_cast<bf16*>(smem);
+  bf16* Vs = Ks + kchunk * C::LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int D = H * DH;
+  const long ldg = 3L * D;
+  const bf16* qb = qkv + (long)b * S * ldg + h * DH;
+  const bf16* kb_ = qb + D;
+  const bf16* vb_ = qb + 2 * D;
+  const int qtiles = (S + 31) / 32, npass = (qtiles + 3) / 4, nstage = (S + kchunk - 1) / kchunk;
+
+  for (int pass = 0; pass < npass; ++pass) {
+    const int qt = pass * 4 + wave;
+    const bool active = qt < qtiles;
+    bf16x8 qf[2][C::KS];
+    f32x4 o[2][C::DT];
+    float m[2], lsum[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      m[u] = NEG_BIG; lsum[u] = 0.f;
+#pragma unroll
+      for (int s = 0; s < C::KS; ++s) qf[u][s] = row_frag_gmem<DH>(qb, ldg, qt * 32 + u * 16 + c16, active ? S : 0, s, lane);
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) o[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int st = 0; st < nstage; ++st) {
+      const int k0 = st * kchunk;
+      const int krows = min(kchunk, ((S - k0 + 31) / 32) * 32);
+      if (nstage > 1 || pass == 0) {
+        __syncthreads();
+        stage_rows<DH>(Ks, kb_, ldg, k0, krows, S, tid);
+        stage_rows<DH>(Vs, vb_, ldg, k0, krows, S, tid);
+        __syncthreads();
+      }
+      if (active) {
+        for (int kb = 0; kb < krows; kb += 32) {
+          f32x4 sc[2][2];
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            bf16x8 kf[C::KS];
+#pragma unroll
+            for (int s = 0; s < C::KS; ++s) kf[s] = row_frag_lds<DH>(Ks, kb + kt * 16 + c16, s, lane);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int s = 0; s < C::KS; ++s) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[s], qf[u][s], a, 0, 0, 0);
+              sc[u][kt] = a;
+            }
+          }
+          bf16x8 pb[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int key = k0 + kb + kt * 16 + 4 * g + r;
+                float x = sc[u][kt][r] * scale_log2;
+                x = key < S ? x : NEG_BIG;
+                sc[u][kt][r] = x;
+                mx = fmaxf(mx, x);
+              }
+            mx = group4_max(mx);
+            const float mn = fmaxf(m[u], mx);
+            const float alpha = exp2f(m[u] - mn);
+            m[u] = mn;
+            float rs = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float pv = exp2f(sc[u][kt][r] - mn);
+                sc[u][kt][r] = pv;
+                rs += pv;
+              }
+            lsum[u] = lsum[u] * alpha + rs;
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) o[u][dt] *= alpha;
+            pb[u] = pack_b(sc[u][0], sc[u][1]);
+          }
+#pragma unroll
+          for (int dt = 0; dt < C::DT; ++dt) {
+            const bf16x8 vt = tr_frag(Vs, C::LD, kb, dt * 16, lane);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pb[u], o[u][dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float l = group4_sum(lsum[u]);
+        const float inv = 1.0f / l;
+        const int q = qt * 32 + u * 16 + c16;
+        if (q < S) {
+#pragma unroll
+          for (int dt = 0; dt < C::DT; ++dt) {
+            bf16x4 w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = (bf16)(o[u][dt][r] * inv);
+            *reinterpret_cast<bf16x4*>(out + ((long)b * S + q) * D + h * DH + dt * 16 + 4 * g) = w;
+          }
+          if (g == 0) lse[((long)b * H + h) * S + q] = (m[u] + log2f(l)) * LN2;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                               const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                               bf16* __restrict__ dqkv, int S, int H, int spad,
+                                                               float scale) {
+  using C = AttCfg<DH>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16* I0 = reinterpret_cast<bf16*>(smem);            // phase A: Q   | phase B: K
+  bf16* I1 = I0 + spad * C::LD;                        // phase A: dO  | phase B: V
+  float* lse_s = reinterpret_cast<float*>(I1 + spad * C::LD);   // [spad], pre-multiplied by log2(e)
+  float* del_s = lse_s + spad;                                   // [spad]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int D = H * DH;
+  const long ldg = 3L * D;
+  const bf16* qb = qkv + (long)b * S * ldg + h * DH;
+  const bf16* kb_ = qb + D;
+  const bf16* vb_ = qb + 2 * D;
+  const bf16* ob = out + (long)b * S * D + h * DH;
+  const bf16* dob = dout + (long)b * S * D + h * DH;
+  bf16* dqb = dqkv + (long)b * S * ldg + h * DH;
+  const float scale_log2 = scale * LOG2E;
+  const int nblk = spad / 32;
+
+  // ---- stage Q, dO; delta[q] = sum_d dO*O; lse ------------------------------------------------
+  stage_rows<DH>(I0, qb, ldg, 0, spad, S, tid);
+  stage_rows<DH>(I1, dob, (long)D, 0, spad, S, tid);
+  for (int q = tid; q < spad; q += ATT_THREADS) {
+    float dl = 0.f, ls = 0.f;
+    if (q < S) {
+#pragma unroll
+      for (int c = 0; c < C::CPR; ++c) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(dob + (long)q * D + c * 8);
+        const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(ob + (long)q * D + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)a[e] * (float)o8[e];
+      }
+      ls = lse[((long)b * H + h) * S + q] * LOG2E;
+    }
+    del_s[q] = dl;
+    lse_s[q] = ls;
+  }
+  __syncthreads();
+
+  // ---- phase A: wave owns 32 keys, sweeps queries; dV^T, dK^T in registers ---------------------
+  for (int kblk = wave; kblk < nblk; kblk += 4) {
+    bf16x8 kf[2][C::KS], vf[2][C::KS];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s = 0; s < C::KS; ++s) {
+        kf[kt][s] = row_frag_gmem<DH>(kb_, ldg, kblk * 32 + kt * 16 + c16, S, s, lane);
+        vf[kt][s] = row_frag_gmem<DH>(vb_, ldg, kblk * 32 + kt * 16 + c16, S, s, lane);
+      }
+    f32x4 dv[C::DT][2], dk[C::DT][2];
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) { dv[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int qblk = 0; qblk < nblk; ++qblk) {
+      f32x4 p[2][2], ds[2][2];   // [u][kt]
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        bf16x8 qa[C::KS], da[C::KS];
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s) {
+          qa[s] = row_frag_lds<DH>(I0, qblk * 32 + u * 16 + c16, s, lane);
+          da[s] = row_frag_lds<DH>(I1, qblk * 32 + u * 16 + c16, s, lane);
+        }
+        float lq[4], dq_[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          lq[r] = lse_s[qblk * 32 + u * 16 + 4 * g + r];
+          dq_[r] = del_s[qblk * 32 + u * 16 + 4 * g + r];
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < C::KS; ++s) {
+            sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[s], kf[kt][s], sa, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[s], vf[kt][s], dp, 0, 0, 0);
+          }
+          const int key = kblk * 32 + kt * 16 + c16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = qblk * 32 + u * 16 + 4 * g + r;
+            float pv = exp2f(sa[r] * scale_log2 - lq[r]);
+            pv = (key < S && q < S) ? pv : 0.f;
+            p[u][kt][r] = pv;
+            ds[u][kt][r] = pv * (dp[r] - dq_[r]) * scale;
+          }
+        }
+      }
+      bf16x8 pB[2], dsB[2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) { pB[kt] = pack_b(p[0][kt], p[1][kt]); dsB[kt] = pack_b(ds[0][kt], ds[1][kt]); }
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        const bf16x8 doT = tr_frag(I1, C::LD, qblk * 32, dt * 16, lane);
+        const bf16x8 qT = tr_frag(I0, C::LD, qblk * 32, dt * 16, lane);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          dv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doT, pB[kt], dv[dt][kt], 0, 0, 0);
+          dk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, dsB[kt], dk[dt][kt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const int key = kblk * 32 + kt * 16 + c16;
+      if (key < S) {
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+          bf16x4 wk, wv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { wk[r] = (bf16)dk[dt][kt][r]; wv[r] = (bf16)dv[dt][kt][r]; }
+          *reinterpret_cast<bf16x4*>(dqb + (long)key * ldg + D + dt * 16 + 4 * g) = wk;
+          *reinterpret_cast<bf16x4*>(dqb + (long)key * ldg + 2 * D + dt * 16 + 4 * g) = wv;
+        }
+      }
+    }
+  }
+
+  // ---- phase B: restage K, V; wave owns 32 queries, sweeps keys; dQ^T in registers ---------------
+  __syncthreads();
+  stage_rows<DH>(I0, kb_, ldg, 0, spad, S, tid);
+  stage_rows<DH>(I1, vb_, ldg, 0, spad, S, tid);
+  __syncthreads();
+  for (int qblk = wave; qblk < nblk; qblk += 4) {
+    bf16x8 qf[2][C::KS], dof[2][C::KS];
+    float lq[2], dl[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = qblk * 32 + u * 16 + c16;
+#pragma unroll
+      for (int s = 0; s < C::KS; ++s) {
+        qf[u][s] = row_frag_gmem<DH>(qb, ldg, q, S, s, lane);
+        dof[u][s] = row_frag_gmem<DH>(dob, (long)D, q, S, s, lane);
+      }
+      lq[u] = lse_s[q];
+      dl[u] = del_s[q];
+    }
+    f32x4 dq[C::DT][2];
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) dq[dt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kblk = 0; kblk < nblk; ++kblk) {
+      f32x4 ds[2][2];  // [u][kt]
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        bf16x8 ka[C::KS], va[C::KS];
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s) {
+          ka[s] = row_frag_lds<DH>(I0, kblk * 32 + kt * 16 + c16, s, lane);
+          va[s] = row_frag_lds<DH>(I1, kblk * 32 + kt * 16 + c16, s, lane);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < C::KS; ++s) {
+            sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[s], qf[u][s], sa, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[s], dof[u][s], dp, 0, 0, 0);
+          }
+          const int q = qblk * 32 + u * 16 + c16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kblk * 32 + kt * 16 + 4 * g + r;
+            float pv = exp2f(sa[r] * scale_log2 - lq[u]);
+            pv = (key < S && q < S) ? pv : 0.f;
+            ds[u][kt][r] = pv * (dp[r] - dl[u]) * scale;
+          }
+        }
+      }
+      bf16x8 dsB[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) dsB[u] = pack_b(ds[u][0], ds[u][1]);
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        const bf16x8 kT = tr_frag(I0, C::LD, kblk * 32, dt * 16, lane);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) dq[dt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, dsB[u], dq[dt][u], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = qblk * 32 + u * 16 + c16;
+      if (q < S) {
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+          bf16x4 w;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) w[r] = (bf16)dq[dt][u][r];
+          *reinterpret_cast<bf16x4*>(dqb + (long)q * ldg + dt * 16 + 4 * g) = w;
+        }
+      }
+    }
+  }
+}
+
+constexpr size_t ATT_LDS_FWD_BUDGET = 72 * 1024;   // S=197, dh=64 (224 rows) in one stage, 2 WG/CU
+constexpr size_t ATT_LDS_MAX = 160 * 1024;
+
+template <int DH> size_t bwd_lds_bytes(int S) {
+  const int spad = (S + 31) / 32 * 32;
+  return (size_t)2 * spad * AttCfg<DH>::LD * 2 + (size_t)2 * spad * sizeof(float);
+}
+
+template <int DH>
+int launch_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, hipStream_t st) {
+  const int spad = (S + 31) / 32 * 32;
+  int kchunk = (int)(ATT_LDS_FWD_BUDGET / (2 * AttCfg<DH>::LD * 2)) / 32 * 32;
+  if (kchunk > spad) kchunk = spad;
+  const size_t lds = (size_t)2 * kchunk * AttCfg<DH>::LD * 2;
+  const float scale_log2 = LOG2E / sqrtf((float)DH);
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  attn_fwd_kernel<DH><<<B * H, ATT_THREADS, lds, st>>>((const bf16*)qkv, (bf16*)out, lse, S, H, kchunk, scale_log2);
+  return iq_launch_status();
+}
+
+template <int DH>
+int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int S, int H,
+               hipStream_t st) {
+  const int spad = (S + 31) / 32 * 32;
+  const size_t lds = bwd_lds_bytes<DH>(S);
+  if (lds > ATT_LDS_MAX) return IQ_ERR_UNSUPPORTED;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  attn_bwd_kernel<DH><<<B * H, ATT_THREADS, lds, st>>>((const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse,
+                                                       (bf16*)dqkv, S, H, spad, 1.0f / sqrtf((float)DH));
+  return iq_launch_status();
+}
+
+}  // namespace
+
+extern "C" int iq_attn_supported(int S, int dh) {
+  if (S <= 0) return 0;
+  if (dh == 16) return bwd_lds_bytes<16>(S) <= ATT_LDS_MAX;
+  if (dh == 32) return bwd_lds_bytes<32>(S) <= ATT_LDS_MAX;
+  if (dh == 64) return bwd_lds_bytes<64>(S) <= ATT_LDS_MAX;
+  return 0;
+}
+
+extern "C" int iq_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int dh, iq_stream_t stream) {
+  if (B <= 0) return IQ_OK;
+  if (!qkv || !out || !lse || S <= 0 || H <= 0) return IQ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  switch (dh) {
+    case 16: return launch_fwd<16>(qkv, out, lse, B, S, H, st);
+    case 32: return launch_fwd<32>(qkv, out, lse, B, S, H, st);
+    case 64: return launch_fwd<64>(qkv, out, lse, B, S, H, st);
+    default: return IQ_ERR_UNSUPPORTED;
+  }
+}
+
+extern "C" int iq_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
+                           int S, int H, int dh, iq_stream_t stream) {
+  if (B <= 0) return IQ_OK;
+  if (!qkv || !out || !dout || !lse || !dqkv || S <= 0 || H <= 0) return IQ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  switch (dh) {
+    case 16: return launch_bwd<16>(qkv, out, dout, lse, dqkv, B, S, H, st);
+    case 32: return launch_bwd<32>(qkv, out, dout, lse, dqkv, B, S, H, st);
+    case 64: return launch_bwd<64>(qkv, out, dout, lse, dqkv, B, S, H, st);
+    default: return IQ_ERR_UNSUPPORTED;
+  }
+}

@@ -1,0 +1,235 @@
+// bf16 MFMA GEMM  C[M,N] = epilogue(A[M,K] * B[N,K]^T), fp32 accumulate (gfx950).
+//
+// Replaces every nn.Linear forward on the path (multi_head_attention.py:18,28;
+// position_wise_feed_forward.py:13-16), the non-overlapping conv embeddings
+// (V/.../patch_embedding.py:9-15, R/.../patch_embedding.py:29-43) and -- with B pointing at the
+// transposed weight shadow -- their data gradients.
+//
+// Shapes on this path: M = frames*tokens (1e4..1e5), N,K in 128..3072.  Most instances are
+// HBM-bound (K small), so the design goals are: A streamed once per N-tile through L2 (tiles that
+// share an A row-block are consecutive after the XCD remap), every global access a 16 B/lane
+// vector on 128 B rows, the whole elementwise tail (bias, ReLU, positional add, dropout, gate,
+// residual) fused into the epilogue, and bf16 rows stored as contiguous 128 B segments.
+//
+// Tile: 128 x BN (BN = 128 | 64), BK = 64, 4 waves (2x2), mfma_f32_16x16x32_bf16.
+// LDS tile rows are 128 B; 16 B chunk c of row r lives at chunk c ^ ((r>>1)&7), which makes the
+// ds_read_b128 fragment reads (16 rows x one chunk column per lane group) bank-conflict free.
+// Epilogue: each wave stages 16-row strips of its accumulators through a private fp32 LDS strip
+// so that a lane owns 8..16 consecutive columns of one row.
+#include "common.h"
+#include "iqvit.h"
+
+namespace {
+
+constexpr int BM = 128, BK = 64, GEMM_THREADS = 256;
+
+struct GemmParams {
+  const bf16* A; const bf16* B; bf16* C;
+  int lda, ldb, ldc, M, N, K;
+  const float* bias; int relu;
+  const float* pe; int tok, seq, cls_off;
+  int drop_on; IqRng rng; uint32_t thresh; float dscale;
+  const bf16* gate; int ldg; float gate_scale;
+  const bf16* residual; int ldr;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+template <int BN>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(const GemmParams p) {
+  constexpr int WN = BN / 2;        // wave tile columns
+  constexpr int NT = WN / 16;       // 16-col MFMA tiles per wave
+  constexpr int MT = 4;             // 16-row MFMA tiles per wave (wave tile rows = 64)
+  constexpr int A_CH = BM * 8 / GEMM_THREADS;  // 16 B chunks per thread
+  constexpr int B_CH = BN * 8 / GEMM_THREADS;
+  constexpr int STRIP_LD = WN + 4;  // floats
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16* As = reinterpret_cast<bf16*>(smem);                 // [BM][64]
+  bf16* Bs = reinterpret_cast<bf16*>(smem + BM * BK * 2);   // [BN][64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int t = xcd_remap(blockIdx.x, ntiles);
+  const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 ra[A_CH], rb[B_CH];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int c = 0; c < A_CH; ++c) {
+      const int id = tid + c * GEMM_THREADS, row = id >> 3, kc = id & 7;
+      const int gm = m0 + row, gk = k0 + kc * 8;
+      bf16x8 v = {};
+      if (gm < p.M && gk < p.K) v = *reinterpret_cast<const bf16x8*>(p.A + (long)gm * p.lda + gk);
+      ra[c] = v;
+    }
+#pragma unroll
+    for (int c = 0; c < B_CH; ++c) {
+      const int id = tid + c * GEMM_THREADS, row = id >> 3, kc = id & 7;
+      const int gn = n0 + row, gk = k0 + kc * 8;
+      bf16x8 v = {};
+      if (gn < p.N && gk < p.K) v = *reinterpret_cast<const bf16x8*>(p.B + (long)gn * p.ldb + gk);
+      rb[c] = v;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int c = 0; c < A_CH; ++c) {
+      const int id = tid + c * GEMM_THREADS, row = id >> 3, kc = id & 7;
+      *reinterpret_cast<bf16x8*>(As + row * BK + swz(row, kc) * 8) = ra[c];
+    }
+#pragma unroll
+    for (int c = 0; c < B_CH; ++c) {
+      const int id = tid + c * GEMM_THREADS, row = id >> 3, kc = id & 7;
+      *reinterpret_cast<bf16x8*>(Bs + row * BK + swz(row, kc) * 8) = rb[c];
+    }
+  };
+
+  const int nk = (p.K + BK - 1) / BK;
+  gload(0);
+  lstore();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[MT], bfr[NT];
+      const int ch = s * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = wm * 64 + i * 16 + (lane & 15);
+        af[i] = *reinterpret_cast<const bf16x8*>(As + row * BK + swz(row, ch) * 8);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int row = wn * WN + j * 16 + (lane & 15);
+        bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + row * BK + swz(row, ch) * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      lstore();
+      __syncthreads();
+    }
+  }
+
+  const IqRng rng = p.drop_on ? rng_resolve(p.rng) : p.rng;
+  // ---- epilogue: accumulators -> wave-private fp32 strip -> row-contiguous vectors -> HBM ----
+  float* strip = reinterpret_cast<float*>(smem) + wave * (16 * STRIP_LD);
+  constexpr int CPL = WN / 4;       // columns per lane (16 | 8)
+  const int er = lane >> 2, ec = (lane & 3) * CPL;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) strip[((lane >> 4) * 4 + r) * STRIP_LD + j * 16 + (lane & 15)] = acc[i][j][r];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    float v[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL / 4; ++q) {
+      const f32x4 tq = *reinterpret_cast<const f32x4*>(strip + er * STRIP_LD + ec + q * 4);
+      v[q * 4 + 0] = tq[0]; v[q * 4 + 1] = tq[1]; v[q * 4 + 2] = tq[2]; v[q * 4 + 3] = tq[3];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int gm = m0 + wm * 64 + i * 16 + er;
+    const int gn = n0 + wn * WN + ec;
+    if (gm < p.M) {
+      long orow = gm;
+      int prow = 0;
+      if (p.tok > 0) {
+        const int f = gm / p.tok, tk = gm - f * p.tok;
+        prow = tk + p.cls_off;
+        orow = (long)f * p.seq + prow;
+      }
+#pragma unroll
+      for (int h = 0; h < CPL / 8; ++h) {
+        const int col = gn + h * 8;
+        if (col < p.N) {
+          float* w = v + h * 8;
+          if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] += p.bias[col + e];
+          }
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = fmaxf(w[e], 0.f);
+          }
+          if (p.pe) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] += p.pe[(long)prow * p.N + col + e];
+          }
+          if (p.drop_on) {
+            const uint32_t keep = dropout_keep8(rng, (uint64_t)(orow * p.N + col) >> 3, p.thresh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = ((keep >> e) & 1u) ? w[e] * p.dscale : 0.f;
+          }
+          if (p.gate) {
+            const bf16x8 g = *reinterpret_cast<const bf16x8*>(p.gate + (long)gm * p.ldg + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = ((float)g[e] > 0.f) ? w[e] * p.gate_scale : 0.f;
+          }
+          if (p.residual) {
+            const bf16x8 rr = *reinterpret_cast<const bf16x8*>(p.residual + orow * p.ldr + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] += (float)rr[e];
+          }
+          *reinterpret_cast<bf16x8*>(p.C + orow * p.ldc + col) = pack8(w);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                               const iq_epilogue_t* epi, iq_stream_t stream) {
+  if (M <= 0 || N <= 0) return IQ_OK;
+  if (!A || !B || !C || K <= 0) return IQ_ERR_ARG;
+  if ((K % 8) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return IQ_ERR_UNSUPPORTED;
+  GemmParams p = {};
+  p.A = (const bf16*)A; p.B = (const bf16*)B; p.C = (bf16*)C;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+  if (epi) {
+    p.bias = epi->bias; p.relu = epi->relu;
+    p.pe = epi->pe; p.tok = epi->tok; p.seq = epi->seq; p.cls_off = epi->cls_off;
+    if (epi->tok < 0 || (epi->tok > 0 && epi->seq < epi->tok + epi->cls_off)) return IQ_ERR_ARG;
+    if (epi->drop.p > 0.f) {
+      if (epi->drop.p >= 1.f) return IQ_ERR_ARG;
+      p.drop_on = 1;
+      p.rng.seed = epi->drop.seed; p.rng.step = epi->drop.step; p.rng.site = epi->drop.site;
+      p.rng.step_dev = epi->drop.step_dev;
+      p.thresh = dropout_thresh(epi->drop.p);
+      p.dscale = dropout_scale(epi->drop.p);
+    }
+    p.gate = (const bf16*)epi->gate; p.ldg = epi->ldg; p.gate_scale = epi->gate_scale;
+    p.residual = (const bf16*)epi->residual; p.ldr = epi->ldr;
+    if ((p.gate && (p.ldg % 8)) || (p.residual && (p.ldr % 8))) return IQ_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  p.tiles_m = (M + BM - 1) / BM;
+  if (N % 128 == 0 || N > 512) {
+    p.tiles_n = (N + 127) / 128;
+    const size_t lds = (size_t)(BM + 128) * BK * 2;
+    gemm_nt_kernel<128><<<p.tiles_m * p.tiles_n, GEMM_THREADS, lds, st>>>(p);
+  } else {
+    p.tiles_n = (N + 63) / 64;
+    const size_t lds = (size_t)(BM + 64) * BK * 2;
+    gemm_nt_kernel<64><<<p.tiles_m * p.tiles_n, GEMM_THREADS, lds, st>>>(p);
+  }
+  return iq_launch_status();
+}
