@@ -244,6 +244,7 @@ class NativePlan:
         named = self._named()
         flat = torch.zeros(self.nparam, dtype=torch.float32, device=device)
         first = None
+        bound = []
         with torch.no_grad():
             for name, off, shape in self.entries:
                 key = name[len(self.strip):] if self.strip and name.startswith(self.strip) else name
@@ -256,10 +257,12 @@ class NativePlan:
                 view = flat[off:off + n].view(shape)
                 view.copy_(p.data.to(device=device, dtype=torch.float32))
                 p.data = view
+                bound.append(p)
                 if first is None:
                     first = p
         self.flat = flat
         self._probe = first
+        self._bound = bound
         pe = self._pe()
         if pe.device != device or pe.dtype != torch.float32 or not pe.is_contiguous():
             raise N.IqError("positional encoding buffer must be a contiguous fp32 tensor on the model's device")
@@ -278,10 +281,19 @@ class NativePlan:
         if (self.flat is None or self.flat.device != device or p is None
                 or p.data.untyped_storage().data_ptr() != self.flat.untyped_storage().data_ptr()):
             self.bind(device)
-        v = self.flat._version
+        # `p.data = view` does not share version counters with the flat buffer, so sum the parameters'
+        # own counters: every in-place update (optimizer step, load_state_dict, p.add_()) bumps one.
+        # Writes through `p.data` are invisible to autograd versions: call mark_dirty() after those.
+        v = 0
+        for q in self._bound:
+            v += q._version
         if v != self.shadow_version:
             N.check(self.L.iq_model_refresh_shadow(self.h, N.stream_handle()), "refresh_shadow", self.h)
             self.shadow_version = v
+
+    def mark_dirty(self):
+        """Force a bf16 shadow refresh on the next forward (after writing parameters via `.data`)."""
+        self.shadow_version = -1
 
     def workspace(self, batch: int, device) -> torch.Tensor:
         need = self.L.iq_model_workspace_bytes(self.h, batch, 1)
