@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Headline benchmark: IQ frames/s of one full training step (forward + label-smoothed CE + backward +
+gradient all-reduce + clip + AdamW) on synthetic frames already resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W [--config B|C|Cp|D|A|ref] [--batch per-GPU]
+  N>1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Default workload = BASELINE.json configs[1]: ViT-Tiny/16 on 224x224 single-channel frames, 19 classes,
+256 frames per GPU, dropout 0.1 ON, bf16 activations / fp32 master weights.  Weak scaling: per-GPU batch fixed.
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel family, timed live with HIP event pairs on the launch stream
+                  (iq_prof_* in include/iqvit.h) over profiled steps of the same workload
+  cpu_baseline -- the CPU oracle (oracle/iq_oracle.py, "port") timed on this host's cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+import torch.distributed as dist
+
+CONFIGS = {
+    # name: (kind, ctor kwargs, per-GPU batch, drop_prob, weight_decay, description)
+    "B": ("vit", dict(in_channels=1, img_size_h=224, img_size_w=224, patch_size=16, num_classes=19, d_model=192,
+                      n_head=3, n_layers=12, ffn_hidden=768), 256, 0.1, 1e-3,
+          "ViT-Tiny/16 224x224 C=1 19cls (BASELINE configs[1])"),
+    "C": ("rawiq", dict(in_channels=2, seq_length=1024, num_classes=19, d_model=128, n_head=8, n_layers=6,
+                        ffn_hidden=1024, use_cls_token=True, embedding_type="segment", segment_size=16), 256, 0.2, 1e-4,
+          "transformer_rawIQ seg16 d128 h8 L6 F1024 (BASELINE configs[2])"),
+    "Cp": ("rawiq", dict(in_channels=2, seq_length=1024, num_classes=19, d_model=256, n_head=8, n_layers=9,
+                         ffn_hidden=1024, use_cls_token=True, embedding_type="segment", segment_size=16), 128, 0.1, 1e-3,
+           "transformer_rawIQ published best d256 L9"),
+    "D": ("vit", dict(in_channels=1, img_size_h=224, img_size_w=224, patch_size=16, num_classes=19, d_model=768,
+                      n_head=12, n_layers=12, ffn_hidden=3072), 512, 0.1, 1e-3,
+          "ViT-Base/16 224x224 (BASELINE configs[3], 512/GPU)"),
+    "A": ("vit", dict(in_channels=1, img_size_h=32, img_size_w=32, patch_size=16, num_classes=11, d_model=128,
+                      n_head=8, n_layers=2, ffn_hidden=512), 256, 0.1, 1e-3, "ViT 32x32 p16 (BASELINE configs[0])"),
+    "ref": ("vit", dict(in_channels=1, img_size_h=32, img_size_w=64, patch_size=4, num_classes=19, d_model=128,
+                        n_head=8, n_layers=6, ffn_hidden=512), 256, 0.1, 1e-3, "reference train.py default ViT 32x64 p4"),
+}
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0    # dense bf16
+RIDGE = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+FAMILIES = ["gemm_nt", "wgrad", "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd", "misc", "optimizer"]
+
+
+def geometry(kind, kw):
+    D, F, L, H = kw["d_model"], kw["ffn_hidden"], kw["n_layers"], kw["n_head"]
+    if kind == "vit":
+        tok = (kw["img_size_h"] // kw["patch_size"]) * (kw["img_size_w"] // kw["patch_size"])
+        P = kw["in_channels"] * kw["patch_size"] ** 2
+        S = tok + 1
+    else:
+        k = 1 if kw["embedding_type"] == "conv1d" else kw["segment_size"]
+        tok = kw["seq_length"] // k
+        P = kw["in_channels"] * k
+        S = tok + (1 if kw["use_cls_token"] else 0)
+    return dict(D=D, F=F, L=L, H=H, dh=D // H, tok=tok, P=P, Ppad=(P + 31) // 32 * 32, S=S, K=kw["num_classes"])
+
+
+def family_work(g, B, training_dropout):
+    """Algorithmic bytes / flops per training step and launches per step for each kernel family
+    (DESIGN.md section 'Kernels and rooflines' derives the same numbers)."""
+    D, F, L, H, dh, S, tok, Ppad = g["D"], g["F"], g["L"], g["H"], g["dh"], g["S"], g["tok"], g["Ppad"]
+    M, MT = B * S, B * tok
+    nt = []   # (M, N, K, extra_MN_reads)
+    nt.append((MT, D, Ppad, 0))                 # embedding
+    for _ in range(L):
+        nt += [(M, 3 * D, D, 0), (M, D, D, 1), (M, F, D, 0), (M, D, F, 1)]            # fwd: qkv, out(+res), ffn1, ffn2(+res)
+        nt += [(M, F, D, 1), (M, D, F, 1), (M, D, D, 0), (M, D, 3 * D, 1)]            # dgrad: ffn2(+gate), ffn1(+res), out, qkv(+res)
+    b_nt = sum(2 * (m * k + n * k + m * n) + 2 * m * n * ex for m, n, k, ex in nt)
+    f_nt = sum(2 * m * n * k for m, n, k, ex in nt)
+    wg = [(MT, D, Ppad)]
+    for _ in range(L):
+        wg += [(M, D, F), (M, F, D), (M, D, D), (M, 3 * D, D)]
+    b_wg = sum(2 * (m * n + m * k) + 4 * n * k for m, n, k in wg)
+    f_wg = sum(2 * m * n * k for m, n, k in wg)
+    b_af = L * (2 * M * 3 * D + 2 * M * D + 4 * B * H * S)
+    f_af = L * 4 * B * H * S * S * dh
+    b_ab = L * (2 * M * 3 * D * 2 + 2 * M * D * 2 + 4 * B * H * S)
+    f_ab = L * 14 * B * H * S * S * dh          # 7 MFMA products (S and dP are computed in both phases)
+    b_lf = 2 * L * (2 * M * D * 2 + 8 * M)
+    b_lb = 2 * L * (2 * M * D * (3 + (1 if training_dropout else 0)) + 8 * M)
+    return {
+        "gemm_nt": dict(bytes=b_nt, flops=f_nt, launches=len(nt)),
+        "wgrad": dict(bytes=b_wg, flops=f_wg, launches=len(wg)),
+        "attn_fwd": dict(bytes=b_af, flops=f_af, launches=L),
+        "attn_bwd": dict(bytes=b_ab, flops=f_ab, launches=L),
+        "ln_fwd": dict(bytes=b_lf, flops=0, launches=2 * L),
+        "ln_bwd": dict(bytes=b_lb, flops=0, launches=2 * L),
+    }
+
+
+def train_flops_per_frame(g):
+    D, F, L, S, tok, P, K = g["D"], g["F"], g["L"], g["S"], g["tok"], g["P"], g["K"]
+    fwd = L * (8 * S * D * D + 4 * S * S * D + 4 * S * D * F) + 2 * tok * P * D + 2 * D * K
+    return 3 * fwd
+
+
+def cpu_baseline(kind, kw, drop, wd, budget_s=20.0):
+    """The CPU oracle's full training step (dropout ON, clip, AdamW) on this host, bounded sample."""
+    import iq_oracle as O
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(ncpu, 16)))   # a 1-GPU box owns 16 host cores; more threads oversubscribe (measured)
+    cfg = O.OracleConfig(kind=kind, drop_prob=drop, **kw)
+    sd = O.init_state(cfg, 0)
+    st = O.adamw_init(sd)
+    g = torch.Generator().manual_seed(0)
+    b = 8 if kw["d_model"] <= 256 else 2
+    shape = (b, kw["in_channels"], kw["img_size_h"], kw["img_size_w"]) if kind == "vit" else (b, kw["in_channels"], kw["seq_length"])
+    x = torch.randn(*shape, generator=g)
+    y = torch.randint(0, kw["num_classes"], (b,), generator=g)
+    O.train_step(cfg, sd, st, x, y, weight_decay=wd)        # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        O.train_step(cfg, sd, st, x, y, weight_decay=wd)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    return {"value": round(n * b / el, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} full training steps of batch {b} (same model/config, fp32, dropout on) after 1 warm-up, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="B", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--graph", type=int, default=-1, help="hipGraph replay of the step (default: on for 1 GPU)")
+    ap.add_argument("--buckets", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--prof-steps", type=int, default=5)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    if a.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    import vit_vs_raw_iq_amd as P
+    from vit_vs_raw_iq_amd.trainer import FusedTrainer
+    import vit_vs_raw_iq_amd._native as N
+
+    kind, kw, batch, drop, wd, desc = CONFIGS[a.config]
+    B = a.batch or batch
+    torch.manual_seed(0)                       # identical init on every rank (verified seed-deterministic)
+    cls = P.AMCTransformerViT if kind == "vit" else P.AMCTransformerRawIQ
+    model = cls(drop_prob=drop, device="cuda", **kw).to(dev).train()
+    use_graph = (world == 1) if a.graph < 0 else bool(a.graph)
+    tr = FusedTrainer(model, lr=1e-4, weight_decay=wd, betas=(0.9, 0.99), label_smoothing=0.1, max_norm=1.0,
+                      n_buckets=a.buckets, use_graph=use_graph, dropout_seed=1234)
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    shape = (B, kw["in_channels"], kw["img_size_h"], kw["img_size_w"]) if kind == "vit" else (B, kw["in_channels"], kw["seq_length"])
+    x = torch.randn(*shape, device=dev, generator=g)
+    y = torch.randint(0, kw["num_classes"], (B,), device=dev, generator=g)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(a.warmup, 1)):
+        tr.step(x, y)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tr.step(x, y)
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    loss, acc, _ = tr.read_stats()
+    frames = B * world * a.steps
+    value = frames / el
+
+    geo = geometry(kind, kw)
+    roof = None
+    if rank == 0 and not a.no_roofline:
+        # profiled leg: same workload, eager launches, HIP event pair around every kernel-family call
+        L = N.lib()
+        tr.use_graph = False
+        ms = (C_double8 := (__import__("ctypes").c_double * 8))()
+        cnt = (__import__("ctypes").c_longlong * 8)()
+        tr.step(x, y)
+        torch.cuda.synchronize()
+        L.iq_prof_enable(1)
+        L.iq_prof_collect(ms, cnt)
+        for _ in range(a.prof_steps):
+            tr.step(x, y)
+        L.iq_prof_collect(ms, cnt)
+        L.iq_prof_enable(0)
+        per_step = {f: ms[i] / a.prof_steps for i, f in enumerate(FAMILIES)}
+        work = family_work(geo, B, drop > 0)
+        dom = max(work, key=lambda f: per_step[f])
+        w = work[dom]
+        dur_ms = per_step[dom]
+        ai = w["flops"] / max(w["bytes"], 1)
+        launches = max(int(cnt[FAMILIES.index(dom)]) // a.prof_steps, 1)
+        if ai > RIDGE:
+            ach = w["flops"] / (dur_ms * 1e-3) / 1e12
+            roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None}
+        else:
+            ach = w["bytes"] / (dur_ms * 1e-3) / 1e9
+            roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+        roof["avg_launch_us"] = round(dur_ms * 1e3 / launches, 2)
+        roof["launches_per_step"] = launches
+        roof["algorithmic_bytes_per_launch"] = int(w["bytes"] / launches)
+        roof["family_ms_per_step"] = {f: round(v, 4) for f, v in per_step.items()}
+        tot = sum(per_step.values())
+        print(f"[bench] kernel time per step by family (HIP events, eager): "
+              + ", ".join(f"{f} {v:.3f} ms" for f, v in per_step.items()) + f"; sum {tot:.3f} ms", file=sys.stderr)
+        for f, wk in work.items():
+            d = per_step[f] * 1e-3
+            if d > 0:
+                print(f"[bench]   {f:9s} {wk['bytes'] / d / 1e9:8.1f} GB/s algorithmic  {wk['flops'] / d / 1e12:7.2f} TFLOP/s"
+                      f"  ({wk['launches']} launches/step)", file=sys.stderr)
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(kind, kw, drop, wd)
+
+    if rank == 0:
+        fl = train_flops_per_frame(geo)
+        out = {
+            "metric": "IQ frames/sec training (fwd+loss+bwd+clip+AdamW)", "value": round(value, 1), "unit": "frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": desc, "config_id": a.config, "per_gpu_batch": B, "global_batch": B * world,
+                       "tokens_per_frame": geo["S"], "parallelism": f"dp{world}", "dropout": drop,
+                       "hipgraph": bool(use_graph), "train_gflop_per_frame": round(fl / 1e9, 4),
+                       "model_tflops": round(value * fl / 1e12, 2),
+                       "mfma_frac_of_dense_bf16_peak": round(value * fl / 1e12 / (MFMA_PEAK_TFLOPS * world), 4)},
+            "final_loss": round(loss, 4), "train_acc": round(acc, 4),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -173,6 +173,8 @@ size_t iq_model_workspace_bytes(const iq_model_t* m, int batch, int training);
 /* bind device buffers (caller-owned, must outlive use): params/grads flat fp32, pe fp32 [S,D], shadow bytes */
 int iq_model_bind(iq_model_t* m, float* params, float* grads, const float* pe, void* shadow);
 int iq_model_refresh_shadow(iq_model_t* m, iq_stream_t stream);
+/* same, minus the flat fp32->bf16 mirror (iq_adamw_step has just written it) */
+int iq_model_refresh_transposed(iq_model_t* m, iq_stream_t stream);
 /* forward: src fp32 (B,C,H,W)/(B,C,L); enc_out fp32 [B,S,D] or NULL; logits fp32 [B,K] or NULL */
 int iq_model_forward(iq_model_t* m, const float* src, int batch, void* workspace, size_t ws_bytes, int training,
                      uint64_t seed, uint32_t step, float* enc_out, float* logits, iq_stream_t stream);
@@ -184,6 +186,16 @@ int iq_model_backward(iq_model_t* m, const float* dlogits, const float* denc, in
                       size_t ws_bytes, int accumulate, int stage_hi, int stage_lo, iq_stream_t stream);
 /* flat-gradient range [*off, *off+*len) written by stages [stage_lo, stage_hi] (DDP buckets) */
 int iq_model_grad_range(const iq_model_t* m, int stage_hi, int stage_lo, size_t* off, size_t* len);
+
+/* ---------------------------------------------------------------------------------------
+ * Measurement aid (bench.py roofline leg): when enabled, every entry point above brackets its
+ * launches with a HIP event pair on the launch stream.  iq_prof_collect synchronises and returns, per
+ * kernel family, the summed elapsed milliseconds and the number of bracketed calls.
+ * Families: 0 gemm_nt, 1 wgrad (+slab reduce), 2 attn_fwd, 3 attn_bwd, 4 ln_fwd, 5 ln_bwd,
+ *           6 misc (embedding, head, loss, casts), 7 optimizer (gradnorm, adamw). */
+#define IQ_PROF_FAMILIES 8
+int iq_prof_enable(int on);
+int iq_prof_collect(double* ms, long long* count);
 
 #ifdef __cplusplus
 }

@@ -74,6 +74,7 @@ SIGNATURES = {
     "iq_model_workspace_bytes": (_Z, [_P, _I, _I]),
     "iq_model_bind": (_I, [_P, _P, _P, _P, _P]),
     "iq_model_refresh_shadow": (_I, [_P, _P]),
+    "iq_model_refresh_transposed": (_I, [_P, _P]),
     "iq_model_forward": (_I, [_P, _P, _I, _P, _Z, _I, _U64, _U32, _P, _P, _P]),
     "iq_model_backward": (_I, [_P, _P, _P, _I, _P, _Z, _I, _I, _I, _P]),
     "iq_model_grad_range": (_I, [_P, _I, _I, C.POINTER(_Z), C.POINTER(_Z)]),

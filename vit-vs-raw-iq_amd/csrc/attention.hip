@@ -9,7 +9,7 @@
 // probabilities, 0.47 MB/layer/frame at S=197; here they never leave the chip: backward recomputes
 // them from Q, K and the saved log-sum-exp).
 //
-// One workgroup (4 waves) per (frame, head).  All products are mfma_f32_16x16x32_bf16 and are
+// One workgroup (8 waves) per (frame, head).  All products are mfma_f32_16x16x32_bf16 and are
 // oriented so that every accumulator tile is DIRECTLY the B operand of the product that consumes
 // it (guide 3, "an accumulator tile as the next MFMA's operand"):
 //   forward / backward phase B ("query on the lane"):
@@ -24,10 +24,12 @@
 // Softmax statistics fp32, exp2 domain.  dh in {16,32,64}; dh=16 zero-pads the QK^T contraction.
 #include "common.h"
 #include "iqvit.h"
+#include "prof.h"
 
 namespace {
 
-constexpr int ATT_THREADS = 256;
+constexpr int ATT_THREADS = 512;   // 8 waves: S=197 has 7 blocks of 32 -> one pass per phase
+constexpr int ATT_WAVES = ATT_THREADS / 64;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float NEG_BIG = -1.0e30f;
@@ -114,10 +116,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16* __res
   const bf16* qb = qkv + (long)b * S * ldg + h * DH;
   const bf16* kb_ = qb + D;
   const bf16* vb_ = qb + 2 * D;
-  const int qtiles = (S + 31) / 32, npass = (qtiles + 3) / 4, nstage = (S + kchunk - 1) / kchunk;
+  const int qtiles = (S + 31) / 32, npass = (qtiles + ATT_WAVES - 1) / ATT_WAVES, nstage = (S + kchunk - 1) / kchunk;
 
   for (int pass = 0; pass < npass; ++pass) {
-    const int qt = pass * 4 + wave;
+    const int qt = pass * ATT_WAVES + wave;
     const bool active = qt < qtiles;
     bf16x8 qf[2][C::KS];
     f32x4 o[2][C::DT];
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const bf16* __res
   __syncthreads();
 
   // ---- phase A: wave owns 32 keys, sweeps queries; dV^T, dK^T in registers ---------------------
-  for (int kblk = wave; kblk < nblk; kblk += 4) {
+  for (int kblk = wave; kblk < nblk; kblk += ATT_WAVES) {
     bf16x8 kf[2][C::KS], vf[2][C::KS];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const bf16* __res
   stage_rows<DH>(I0, kb_, ldg, 0, spad, S, tid);
   stage_rows<DH>(I1, vb_, ldg, 0, spad, S, tid);
   __syncthreads();
-  for (int qblk = wave; qblk < nblk; qblk += 4) {
+  for (int qblk = wave; qblk < nblk; qblk += ATT_WAVES) {
     bf16x8 qf[2][C::KS], dof[2][C::KS];
     float lq[2], dl[2];
 #pragma unroll
@@ -470,6 +472,7 @@ extern "C" int iq_attn_fwd(const void* qkv, void* out, float* lse, int B, int S,
   if (B <= 0) return IQ_OK;
   if (!qkv || !out || !lse || S <= 0 || H <= 0) return IQ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  IQ_PROF(IQ_FAM_ATTN_FWD, st);
   switch (dh) {
     case 16: return launch_fwd<16>(qkv, out, lse, B, S, H, st);
     case 32: return launch_fwd<32>(qkv, out, lse, B, S, H, st);
@@ -483,6 +486,7 @@ extern "C" int iq_attn_bwd(const void* qkv, const void* out, const void* dout, c
   if (B <= 0) return IQ_OK;
   if (!qkv || !out || !dout || !lse || !dqkv || S <= 0 || H <= 0) return IQ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  IQ_PROF(IQ_FAM_ATTN_BWD, st);
   switch (dh) {
     case 16: return launch_bwd<16>(qkv, out, dout, lse, dqkv, B, S, H, st);
     case 32: return launch_bwd<32>(qkv, out, dout, lse, dqkv, B, S, H, st);

@@ -18,6 +18,7 @@
 // so that a lane owns 8..16 consecutive columns of one row.
 #include "common.h"
 #include "iqvit.h"
+#include "prof.h"
 
 namespace {
 
@@ -221,6 +222,7 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
     if ((p.gate && (p.ldg % 8)) || (p.residual && (p.ldr % 8))) return IQ_ERR_UNSUPPORTED;
   }
   hipStream_t st = (hipStream_t)stream;
+  IQ_PROF(IQ_FAM_GEMM_NT, st);
   p.tiles_m = (M + BM - 1) / BM;
   if (N % 128 == 0 || N > 512) {
     p.tiles_n = (N + 127) / 128;

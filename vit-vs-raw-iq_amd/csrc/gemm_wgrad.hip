@@ -15,10 +15,11 @@
 // reproducible; float atomics would be both slower at this byte rate and order dependent).
 #include "common.h"
 #include "iqvit.h"
+#include "prof.h"
 
 namespace {
 
-constexpr int WG_THREADS = 256;
+constexpr int WG_THREADS = 512;   // 8 waves: 2 (n) x 4 (k); two workgroups per CU hide the HBM latency of the single-stage loop
 constexpr int TN = 128;     // output rows (n) per tile
 constexpr int MC = 64;      // contraction rows per LDS stage
 constexpr int YLD = TN + 16;  // padded LDS row (elements): 288 B rows -> conflict-free tr reads
@@ -43,19 +44,20 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int ld, int r0, int 
 }
 
 template <int TK>
-__global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(WG_THREADS, 4) void wgrad_kernel(const WgradParams p) {
   constexpr int XLD = TK + 16;
-  constexpr int KT = TK / 32;       // 16-col k tiles per wave (wave tile = 64 n x TK/2 k)
-  constexpr int Y_CH = MC * (TN / 8) / WG_THREADS;  // 4
-  constexpr int X_CH = MC * (TK / 8) / WG_THREADS;  // 4 | 2
+  constexpr int KT = TK / 64;       // 16-col k tiles per wave (wave tile = 64 n x TK/4 k)
+  constexpr int Y_CH = MC * (TN / 8) / WG_THREADS;  // 2
+  constexpr int X_CH = MC * (TK / 8) / WG_THREADS;  // 2 | 1
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16* Ys = reinterpret_cast<bf16*>(smem);
   bf16* Xs = Ys + MC * YLD;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave >> 1, wk = wave & 1;
+  const int wn = wave >> 2, wk = wave & 3;
   const int ntile = p.tiles_n * p.tiles_k;
-  const int split = blockIdx.x / ntile, tile = blockIdx.x % ntile;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);   // one split's tiles run on one XCD: slab rows re-read from its L2
+  const int split = lid / ntile, tile = lid % ntile;
   const int n0 = (tile / p.tiles_k) * TN, k0 = (tile % p.tiles_k) * TK;
   const int mbeg = split * p.rows_per_split;
   const int mend = min(p.M, mbeg + p.rows_per_split);
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams p) 
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i] = tr_frag(Ys, YLD, s * 32, wn * 64 + i * 16, lane);
 #pragma unroll
-      for (int j = 0; j < KT; ++j) bfr[j] = tr_frag(Xs, XLD, s * 32, wk * (TK / 2) + j * 16, lane);
+      for (int j = 0; j < KT; ++j) bfr[j] = tr_frag(Xs, XLD, s * 32, wk * (TK / 4) + j * 16, lane);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams p) 
       if (n < p.N) {
 #pragma unroll
         for (int j = 0; j < KT; ++j) {
-          const int k = k0 + wk * (TK / 2) + j * 16 + (lane & 15);
+          const int k = k0 + wk * (TK / 4) + j * 16 + (lane & 15);
           if (k < p.K) out[(long)n * p.K + k] = acc[i][j][r];
         }
         if (do_bias && (lane & 15) == 0) p.bslab[(long)split * p.N + n] = accb[i][r];
@@ -152,20 +154,30 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const WgradParams p) 
   }
 }
 
+// out[i] (+)= sum_s slab[s][i].  Block = 64 float4 columns x 4 split slices (coalesced 1 KiB rows, 4x the
+// loads in flight of a one-thread-per-column loop), slices combined through LDS in fixed order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, long n, int splits,
                                                            float* __restrict__ out, int accumulate) {
-  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= n) return;
+  __shared__ f32x4 part[4][64];
+  const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const long i = ((long)blockIdx.x * 64 + col) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (i + 4 <= n) {
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int sp = 0; sp < splits; ++sp) s += *reinterpret_cast<const f32x4*>(slab + (long)sp * n + i);
-    f32x4* o = reinterpret_cast<f32x4*>(out + i);
-    *o = accumulate ? *o + s : s;
-  } else {
-    for (long e = i; e < n; ++e) {
-      float s = 0.f;
-      for (int sp = 0; sp < splits; ++sp) s += slab[(long)sp * n + e];
-      out[e] = accumulate ? out[e] + s : s;
+#pragma unroll 4
+    for (int sp = sl; sp < splits; sp += 4) s += *reinterpret_cast<const f32x4*>(slab + (long)sp * n + i);
+  } else if (i < n) {
+    for (int sp = sl; sp < splits; sp += 4)
+      for (int e = 0; e < 4 && i + e < n; ++e) s[e] += slab[(long)sp * n + i + e];
+  }
+  part[sl][col] = s;
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    f32x4 t = part[0][col] + part[1][col] + part[2][col] + part[3][col];
+    if (i + 4 <= n) {
+      f32x4* o = reinterpret_cast<f32x4*>(out + i);
+      *o = accumulate ? *o + t : t;
+    } else {
+      for (int e = 0; e < 4 && i + e < n; ++e) out[i + e] = accumulate ? out[i + e] + t[e] : t[e];
     }
   }
 }
@@ -213,6 +225,7 @@ extern "C" int iq_gemm_bf16_wgrad(const void* dY, int ldy, const void* X, int ld
   p.bslab = dbias ? ws + (size_t)w.splits * nk : nullptr;
   p.tiles_n = w.tiles_n; p.tiles_k = w.tiles_k; p.splits = w.splits; p.rows_per_split = w.rows_per_split;
   hipStream_t st = (hipStream_t)stream;
+  IQ_PROF(IQ_FAM_WGRAD, st);
   const int grid = w.tiles_n * w.tiles_k * w.splits;
   // slab stride must equal N*K for the reduce kernel; nk padding only affects the bias slab offset
   WgradParams q = p;
@@ -224,7 +237,7 @@ extern "C" int iq_gemm_bf16_wgrad(const void* dY, int ldy, const void* X, int ld
     wgrad_kernel<64><<<grid, WG_THREADS, lds, st>>>(q);
   }
   const long n = (long)N * K;
-  wgrad_reduce_kernel<<<(int)((n / 4 + 255) / 256 + 1), 256, 0, st>>>(p.slab, n, w.splits, dW, accumulate);
-  if (dbias) wgrad_reduce_kernel<<<(N / 4 + 255) / 256 + 1, 256, 0, st>>>(p.bslab, N, w.splits, dbias, accumulate);
+  wgrad_reduce_kernel<<<(int)((n + 255) / 256), 256, 0, st>>>(p.slab, n, w.splits, dW, accumulate);
+  if (dbias) wgrad_reduce_kernel<<<(N + 255) / 256, 256, 0, st>>>(p.bslab, N, w.splits, dbias, accumulate);
   return iq_launch_status();
 }

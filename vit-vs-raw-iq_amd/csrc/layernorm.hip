@@ -9,6 +9,7 @@
 // every global access is a 16 B/lane coalesced vector (guide G13).  No LDS in fwd.
 #include "common.h"
 #include "iqvit.h"
+#include "prof.h"
 
 namespace {
 
@@ -209,7 +210,7 @@ inline bool ln_dispatch(const LnShape& s, F&& f) {
   return false;
 }
 
-constexpr int LN_MAX_BLOCKS = 1024;
+constexpr int LN_MAX_BLOCKS = 512;
 
 inline int ln_grid(int M, int rpb) {
   long nb = ((long)M + rpb - 1) / rpb;
@@ -233,6 +234,7 @@ extern "C" int iq_ln_fwd(const void* z, const float* gamma, const float* beta, v
   if (!z || !gamma || !beta || !x || !mean || !rstd) return IQ_ERR_ARG;
   if (!ln_shape(D, &s)) return IQ_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  IQ_PROF(IQ_FAM_LN_FWD, st);
   bool ok = ln_dispatch(s, [&](auto lpr, auto nv) {
     constexpr int LPR = decltype(lpr)::value, NV = decltype(nv)::value;
     ln_fwd_kernel<LPR, NV><<<ln_grid(M, (64 / LPR) * 4), LN_THREADS, 0, st>>>((const bf16*)z, gamma, beta, (bf16*)x, mean,
@@ -261,6 +263,7 @@ extern "C" int iq_ln_bwd(const void* dx, const void* z, const float* mean, const
     dscale = dropout_scale(drop->p);
   }
   hipStream_t st = (hipStream_t)stream;
+  IQ_PROF(IQ_FAM_LN_BWD, st);
   int rc = IQ_OK;
   bool ok = ln_dispatch(s, [&](auto lpr, auto nv) {
     constexpr int LPR = decltype(lpr)::value, NV = decltype(nv)::value;

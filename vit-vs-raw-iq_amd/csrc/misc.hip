@@ -11,6 +11,7 @@
 //   clip + AdamW ........ ViT/training/train.py:199-201,407-412
 #include "common.h"
 #include "iqvit.h"
+#include "prof.h"
 
 namespace {
 
@@ -88,22 +89,31 @@ __global__ void embed_bwd_gather_kernel(const bf16* __restrict__ dx0, bf16* __re
   }
 }
 
-__global__ void dcls_kernel(const bf16* __restrict__ dx0, float* __restrict__ dcls, int B, int S, int D, int drop_on,
-                            IqRng rng, uint32_t thresh, float dscale, int accumulate) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= D) return;
+// d(cls)[d] = sum_b mask(d(x0)[b,0,d]): block = 8 columns-chunks?  no: block (64 columns x 4 frame slices), LDS combine
+__global__ __launch_bounds__(256) void dcls_kernel(const bf16* __restrict__ dx0, float* __restrict__ dcls, int B, int S, int D,
+                                                   int drop_on, IqRng rng, uint32_t thresh, float dscale, int accumulate) {
+  __shared__ float part[4][64];
+  const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int d = blockIdx.x * 64 + col;
   if (drop_on) rng = rng_resolve(rng);
   float s = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const long off = (long)b * S * D + d;
-    float v = (float)dx0[off];
-    if (drop_on) {
-      const uint32_t keep = dropout_keep8(rng, (uint64_t)off >> 3, thresh);
-      v = ((keep >> (off & 7)) & 1u) ? v * dscale : 0.f;
+  if (d < D) {
+    for (int b = sl; b < B; b += 4) {
+      const long off = (long)b * S * D + d;
+      float v = (float)dx0[off];
+      if (drop_on) {
+        const uint32_t keep = dropout_keep8(rng, (uint64_t)off >> 3, thresh);
+        v = ((keep >> (off & 7)) & 1u) ? v * dscale : 0.f;
+      }
+      s += v;
     }
-    s += v;
   }
-  dcls[d] = accumulate ? dcls[d] + s : s;
+  part[sl][col] = s;
+  __syncthreads();
+  if (sl == 0 && d < D) {
+    const float t = part[0][col] + part[1][col] + part[2][col] + part[3][col];
+    dcls[d] = accumulate ? dcls[d] + t : t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -396,6 +406,7 @@ inline void fill_rng(const iq_dropout_t* d, int* on, IqRng* r, uint32_t* th, flo
 
 extern "C" int iq_patchify(const float* src, void* patches, int kind, int B, int C, int H, int W, int p, int Kpad,
                            iq_stream_t stream) {
+  IQ_PROF(IQ_FAM_MISC, stream);
   if (B <= 0) return IQ_OK;
   if (!src || !patches || C <= 0 || H <= 0 || p <= 0 || (Kpad % 8)) return IQ_ERR_ARG;
   int tok, P;
@@ -416,6 +427,7 @@ extern "C" int iq_patchify(const float* src, void* patches, int kind, int B, int
 
 extern "C" int iq_cls_rows(const float* cls, const float* pe, void* x0, int B, int S, int D, const iq_dropout_t* drop,
                            iq_stream_t stream) {
+  IQ_PROF(IQ_FAM_MISC, stream);
   if (B <= 0) return IQ_OK;
   if (!cls || !pe || !x0 || (D % 8)) return IQ_ERR_ARG;
   int on; IqRng r; uint32_t th; float sc;
@@ -427,6 +439,7 @@ extern "C" int iq_cls_rows(const float* cls, const float* pe, void* x0, int B, i
 
 extern "C" int iq_embed_bwd_gather(const void* dx0, void* demb, float* dcls, int B, int S, int tok, int D, int has_cls,
                                    const iq_dropout_t* drop, int accumulate, iq_stream_t stream) {
+  IQ_PROF(IQ_FAM_MISC, stream);
   if (B <= 0) return IQ_OK;
   if (!dx0 || !demb || (D % 8) || (has_cls && !dcls)) return IQ_ERR_ARG;
   int on; IqRng r; uint32_t th; float sc;
@@ -435,13 +448,14 @@ extern "C" int iq_embed_bwd_gather(const void* dx0, void* demb, float* dcls, int
   hipStream_t st = (hipStream_t)stream;
   embed_bwd_gather_kernel<<<grid_for(n, 256, 4096), 256, 0, st>>>((const bf16*)dx0, (bf16*)demb, B, S, tok, D,
                                                                   has_cls ? 1 : 0, on, r, th, sc);
-  if (has_cls) dcls_kernel<<<(D + 63) / 64, 64, 0, st>>>((const bf16*)dx0, dcls, B, S, D, on, r, th, sc, accumulate);
+  if (has_cls) dcls_kernel<<<(D + 63) / 64, 256, 0, st>>>((const bf16*)dx0, dcls, B, S, D, on, r, th, sc, accumulate);
   return iq_launch_status();
 }
 
 extern "C" int iq_head_fwd(const void* x, const float* ln_g, const float* ln_b, const float* W, const float* b,
                            float* featn, float* hstat, float* logits, int B, int S, int D, int K, int pool,
                            iq_stream_t stream) {
+  IQ_PROF(IQ_FAM_MISC, stream);
   if (B <= 0) return IQ_OK;
   if (!x || !W || !b || !featn || !logits || (ln_g && (!ln_b || !hstat))) return IQ_ERR_ARG;
   head_fwd_kernel<<<B, 64, 0, (hipStream_t)stream>>>((const bf16*)x, ln_g, ln_b, W, b, featn, hstat, logits, S, D, K, pool);
@@ -450,6 +464,7 @@ extern "C" int iq_head_fwd(const void* x, const float* ln_g, const float* ln_b, 
 
 extern "C" int iq_ce_fwd_bwd(const float* logits, const int64_t* labels, int B, int K, float smoothing, float denom,
                              float* loss_sum, int32_t* n_correct, float* dlogits, iq_stream_t stream) {
+  IQ_PROF(IQ_FAM_MISC, stream);
   if (B <= 0) return IQ_OK;
   if (!logits || !labels || K <= 0 || denom <= 0.f) return IQ_ERR_ARG;
   ce_kernel<<<1, 256, 0, (hipStream_t)stream>>>(logits, labels, B, K, smoothing, denom, loss_sum, n_correct, dlogits);
@@ -459,6 +474,7 @@ extern "C" int iq_ce_fwd_bwd(const float* logits, const int64_t* labels, int B, 
 extern "C" int iq_head_bwd(const float* dlogits, const float* featn, const float* hstat, const float* ln_g,
                            const float* ln_b, const float* W, float* dW, float* db, float* dln_g, float* dln_b,
                            void* dx, int B, int S, int D, int K, int pool, int accumulate, iq_stream_t stream) {
+  IQ_PROF(IQ_FAM_MISC, stream);
   if (B <= 0) return IQ_OK;
   if (!dlogits || !featn || !W || !dW || !db || !dx || (D % 8)) return IQ_ERR_ARG;
   if (ln_g && (!ln_b || !hstat || !dln_g || !dln_b)) return IQ_ERR_ARG;
@@ -472,6 +488,7 @@ extern "C" int iq_head_bwd(const float* dlogits, const float* featn, const float
 extern "C" size_t iq_gradnorm_ws_bytes(size_t n) { (void)n; return GN_BLOCKS * sizeof(float); }
 
 extern "C" int iq_gradnorm_sq(const float* g, size_t n, float grad_scale, float* ws, float* out, iq_stream_t stream) {
+  IQ_PROF(IQ_FAM_OPT, stream);
   if (!g || !ws || !out || ((uintptr_t)g & 15)) return IQ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int nb = grid_for(n / 4 + 1, 256 * 4, GN_BLOCKS);
@@ -483,6 +500,7 @@ extern "C" int iq_gradnorm_sq(const float* g, size_t n, float grad_scale, float*
 extern "C" int iq_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, size_t n, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int step, const float* gnorm_sq,
                              float max_norm, float grad_scale, const float* dyn, iq_stream_t stream) {
+  IQ_PROF(IQ_FAM_OPT, stream);
   if (!p || !g || !m || !v || (n % 4)) return IQ_ERR_ARG;
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return IQ_ERR_ARG;
   if (step < 1 && !dyn) return IQ_ERR_ARG;
@@ -497,6 +515,7 @@ extern "C" int iq_counter_add(uint32_t* ctr_u32, uint32_t inc_u32, float* ctr_f3
 }
 
 extern "C" int iq_cast_bf16(const float* src, void* dst, size_t n, iq_stream_t stream) {
+  IQ_PROF(IQ_FAM_MISC, stream);
   if (n == 0) return IQ_OK;
   if (!src || !dst || ((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return IQ_ERR_ARG;
   cast_kernel<<<grid_for(n / 4 + 1, 256, 2048), 256, 0, (hipStream_t)stream>>>(src, (bf16*)dst, n);
@@ -504,6 +523,7 @@ extern "C" int iq_cast_bf16(const float* src, void* dst, size_t n, iq_stream_t s
 }
 
 extern "C" int iq_transpose_cast_bf16(const float* src, void* dst, int rows, int cols, iq_stream_t stream) {
+  IQ_PROF(IQ_FAM_MISC, stream);
   if (rows <= 0 || cols <= 0) return IQ_OK;
   if (!src || !dst) return IQ_ERR_ARG;
   dim3 grid((cols + 31) / 32, (rows + 31) / 32);

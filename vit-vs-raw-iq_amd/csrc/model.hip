@@ -23,6 +23,7 @@
 
 #include "common.h"
 #include "iqvit.h"
+#include "prof.h"
 
 namespace {
 
@@ -86,6 +87,30 @@ __global__ void unpad_kernel(const float* __restrict__ s, float* __restrict__ d,
     d[i] = add ? d[i] + v : v;
   }
 }
+// every transposed weight shadow in ONE launch: table entry = {src float offset, dst byte offset, rows, cols, first tile}
+struct TransDesc { unsigned long long src_off, dst_off; int rows, cols, tile0, tiles_x; };
+__global__ __launch_bounds__(256) void transpose_table_kernel(const float* __restrict__ params, unsigned char* __restrict__ shadow,
+                                                              const TransDesc* __restrict__ tab, int nent) {
+  __shared__ float t[32][33];
+  int e = 0;
+  while (e + 1 < nent && (int)blockIdx.x >= tab[e + 1].tile0) ++e;
+  const TransDesc d = tab[e];
+  const int local = blockIdx.x - d.tile0;
+  const int bx = (local % d.tiles_x) * 32, by = (local / d.tiles_x) * 32;
+  const float* src = params + d.src_off;
+  bf16* dst = reinterpret_cast<bf16*>(shadow + d.dst_off);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = by + i, c = bx + tx;
+    t[i][tx] = (r < d.rows && c < d.cols) ? src[(long)r * d.cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = bx + i, r = by + tx;
+    if (c < d.cols && r < d.rows) dst[(long)c * d.rows + r] = (bf16)t[tx][i];
+  }
+}
+
 __global__ void set_u32_kernel(uint32_t* p, uint32_t v, int bump) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *p = bump ? *p + 1u : v;
 }
@@ -107,7 +132,10 @@ struct iq_model {
   size_t emb_w, emb_b, cls, emb_end;
   std::vector<LayerOff> L;
   size_t hln_g, hln_b, head_w, head_b, head_begin;
-  size_t sh_flat, sh_embw, shadow_bytes;
+  size_t sh_flat, sh_embw, sh_table, shadow_bytes;
+  std::vector<TransDesc> ttab;
+  int ttiles = 0;
+  const void* table_uploaded_to = nullptr;
   float* params = nullptr;
   float* grads = nullptr;
   const float* pe = nullptr;
@@ -299,6 +327,19 @@ extern "C" int iq_model_create(const iq_model_cfg_t* cfg, iq_model_t** out) {
     o.t_w1 = sb; sb = align_up(sb + (size_t)F * D * 2, 256);
     o.t_w2 = sb; sb = align_up(sb + (size_t)D * F * 2, 256);
   }
+  for (auto& o : m->L) {
+    auto push = [&](size_t src, size_t dst, int rows, int cols) {
+      TransDesc d;
+      d.src_off = src; d.dst_off = dst; d.rows = rows; d.cols = cols; d.tile0 = m->ttiles; d.tiles_x = (cols + 31) / 32;
+      m->ttiles += d.tiles_x * ((rows + 31) / 32);
+      m->ttab.push_back(d);
+    };
+    push(o.wqkv, o.t_wqkv, 3 * D, D);
+    push(o.wo, o.t_wo, D, D);
+    push(o.w1, o.t_w1, F, D);
+    push(o.w2, o.t_w2, D, F);
+  }
+  m->sh_table = sb; sb = align_up(sb + m->ttab.size() * sizeof(TransDesc) + 64, 256);
   m->shadow_bytes = sb;
   *out = m;
   return IQ_OK;
@@ -331,24 +372,32 @@ extern "C" int iq_model_bind(iq_model_t* m, float* params, float* grads, const f
   if (!params || !pe || !shadow) return fail(m, IQ_ERR_ARG, "bind: params, pe and shadow are required");
   if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)shadow) & 255) return fail(m, IQ_ERR_ARG, "bind: buffers must be 256 B aligned");
   m->params = params; m->grads = grads; m->pe = pe; m->shadow = (unsigned char*)shadow;
+  if (m->table_uploaded_to != shadow && !m->ttab.empty()) {
+    // one small synchronous copy per (re)binding of the shadow buffer; never on the step path
+    if (hipMemcpy(m->shadow + m->sh_table, m->ttab.data(), m->ttab.size() * sizeof(TransDesc), hipMemcpyHostToDevice) != hipSuccess)
+      return fail(m, IQ_ERR_LAUNCH, "bind: uploading the transpose table failed");
+    m->table_uploaded_to = shadow;
+  }
   return IQ_OK;
 }
 
-extern "C" int iq_model_refresh_shadow(iq_model_t* m, iq_stream_t stream) {
+static int refresh_impl(iq_model_t* m, bool cast_flat, iq_stream_t stream) {
   if (!m || !m->params || !m->shadow) return fail(m, IQ_ERR_ARG, "refresh_shadow: model not bound");
   hipStream_t st = (hipStream_t)stream;
-  const int D = m->c.d_model, F = m->c.ffn_hidden;
-  IQ_TRY(iq_cast_bf16(m->params, m->shadow + m->sh_flat, m->nparam, stream), "cast params");
+  const int D = m->c.d_model;
+  if (cast_flat) IQ_TRY(iq_cast_bf16(m->params, m->shadow + m->sh_flat, m->nparam, stream), "cast params");
+  IQ_PROF(IQ_FAM_MISC, st);
   cast_pad_kernel<<<blocks_for((size_t)D * m->Ppad), 256, 0, st>>>(m->params + m->emb_w, (bf16*)(m->shadow + m->sh_embw), D,
                                                                   m->P, m->Ppad);
-  for (auto& o : m->L) {
-    IQ_TRY(iq_transpose_cast_bf16(m->params + o.wqkv, m->shadow + o.t_wqkv, 3 * D, D, stream), "transpose wqkv");
-    IQ_TRY(iq_transpose_cast_bf16(m->params + o.wo, m->shadow + o.t_wo, D, D, stream), "transpose wo");
-    IQ_TRY(iq_transpose_cast_bf16(m->params + o.w1, m->shadow + o.t_w1, F, D, stream), "transpose w1");
-    IQ_TRY(iq_transpose_cast_bf16(m->params + o.w2, m->shadow + o.t_w2, D, F, stream), "transpose w2");
-  }
+  if (m->ttiles > 0)
+    transpose_table_kernel<<<m->ttiles, 256, 0, st>>>(m->params, m->shadow, (const TransDesc*)(m->shadow + m->sh_table),
+                                                     (int)m->ttab.size());
   return iq_launch_status();
 }
+
+extern "C" int iq_model_refresh_shadow(iq_model_t* m, iq_stream_t stream) { return refresh_impl(m, true, stream); }
+// after iq_adamw_step has already written the flat bf16 mirror: only the transposed / padded copies
+extern "C" int iq_model_refresh_transposed(iq_model_t* m, iq_stream_t stream) { return refresh_impl(m, false, stream); }
 
 extern "C" int iq_model_forward(iq_model_t* m, const float* src, int batch, void* workspace, size_t ws_bytes,
                                 int training, uint64_t seed, uint32_t step, float* enc_out, float* logits,
