@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--prof-steps", type=int, default=5)
+    ap.add_argument("--drop", type=float, default=-1.0, help="override the config's dropout probability (diagnostics)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -164,6 +165,8 @@ def main():
 
     kind, kw, batch, drop, wd, desc = CONFIGS[a.config]
     B = a.batch or batch
+    if a.drop >= 0:
+        drop = a.drop
     torch.manual_seed(0)                       # identical init on every rank (verified seed-deterministic)
     cls = P.AMCTransformerViT if kind == "vit" else P.AMCTransformerRawIQ
     model = cls(drop_prob=drop, device="cuda", **kw).to(dev).train()

@@ -39,7 +39,7 @@ __device__ __forceinline__ bf16x8 pack8(const float* f) {
 }
 
 // ---------------------------------------------------------------------------
-// Philox4x32-10 (Salmon et al. 2011).  counter = (group_lo, group_hi, site, step),
+// Philox4x32 (Salmon et al. 2011), 7 rounds.  counter = (group_lo, group_hi, site, step),
 // key = seed.  One call yields 128 bits = 8 x 16-bit dropout decisions for the 8
 // consecutive elements [8*group, 8*group+8) of a row-major activation.
 // keep  <=>  u16 >= thresh, thresh = round(p * 65536)  (p quantised to 2^-16).
@@ -57,14 +57,22 @@ __device__ __forceinline__ IqRng rng_resolve(IqRng r) {
   return r;
 }
 
-__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                               uint32_t k0, uint32_t k1) {
+// PHILOX_ROUNDS = 7: the smallest round count the Philox authors report as passing BigCrush for
+// Philox4x32 (Salmon et al., SC'11, table 2); 10 is their conservative default.  The rounds are the
+// epilogues' dominant VALU cost (32-bit integer multiplies issue at quarter rate), so the 64-bit
+// product form below lets the compiler use one v_mad_u64_u32 per multiplier instead of mul_lo + mul_hi.
+#ifndef IQ_PHILOX_ROUNDS
+#define IQ_PHILOX_ROUNDS 7
+#endif
+__device__ __forceinline__ u32x4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
-    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+  for (int r = 0; r < IQ_PHILOX_ROUNDS; ++r) {
+    const uint64_t p0 = (uint64_t)M0 * (uint64_t)c0;
+    const uint64_t p1 = (uint64_t)M1 * (uint64_t)c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += W0; k1 += W1;
   }
@@ -74,7 +82,7 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 
 // 8 keep-flags (bit i = element i of the group is kept)
 __device__ __forceinline__ uint32_t dropout_keep8(const IqRng& r, uint64_t group, uint32_t thresh) {
-  u32x4 b = philox4x32_10((uint32_t)group, (uint32_t)(group >> 32), r.site, r.step,
+  u32x4 b = philox4x32((uint32_t)group, (uint32_t)(group >> 32), r.site, r.step,
                           (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
   uint32_t m = 0;
 #pragma unroll

@@ -37,6 +37,89 @@ struct GemmParams {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
+// Epilogue shared by both kernels: accumulators -> wave-private fp32 LDS strip -> one lane owns 8..16
+// consecutive columns of a row -> fused bias / ReLU / PE / dropout / gate / residual -> 16 B bf16 stores.
+// The caller guarantees no LDS tile reads or DMA writes are outstanding.
+template <int BN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][BN / 32], unsigned char* smem, int m0,
+                                              int n0, int lane, int wave) {
+  constexpr int WN = BN / 2;
+  constexpr int NT = WN / 16;
+  constexpr int MT = 4;
+  constexpr int STRIP_LD = WN + 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const IqRng rng = p.drop_on ? rng_resolve(p.rng) : p.rng;
+  float* strip = reinterpret_cast<float*>(smem) + wave * (16 * STRIP_LD);
+  constexpr int CPL = WN / 4;       // columns per lane (16 | 8)
+  const int er = lane >> 2, ec = (lane & 3) * CPL;
+  float bias_r[CPL];                // the lane's columns are the same for every strip: load the bias once
+#pragma unroll
+  for (int e = 0; e < CPL; ++e) {
+    const int col = n0 + wn * WN + ec + e;
+    bias_r[e] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) strip[((lane >> 4) * 4 + r) * STRIP_LD + j * 16 + (lane & 15)] = acc[i][j][r];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    float v[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL / 4; ++q) {
+      const f32x4 tq = *reinterpret_cast<const f32x4*>(strip + er * STRIP_LD + ec + q * 4);
+      v[q * 4 + 0] = tq[0]; v[q * 4 + 1] = tq[1]; v[q * 4 + 2] = tq[2]; v[q * 4 + 3] = tq[3];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int gm = m0 + wm * 64 + i * 16 + er;
+    const int gn = n0 + wn * WN + ec;
+    if (gm < p.M) {
+      long orow = gm;
+      int prow = 0;
+      if (p.tok > 0) {
+        const int f = gm / p.tok, tk = gm - f * p.tok;
+        prow = tk + p.cls_off;
+        orow = (long)f * p.seq + prow;
+      }
+#pragma unroll
+      for (int h = 0; h < CPL / 8; ++h) {
+        const int col = gn + h * 8;
+        if (col < p.N) {
+          float* w = v + h * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] += bias_r[h * 8 + e];
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = fmaxf(w[e], 0.f);
+          }
+          if (p.pe) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] += p.pe[(long)prow * p.N + col + e];
+          }
+          if (p.drop_on) {
+            const uint32_t keep = dropout_keep8(rng, (uint64_t)(orow * p.N + col) >> 3, p.thresh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = ((keep >> e) & 1u) ? w[e] * p.dscale : 0.f;
+          }
+          if (p.gate) {
+            const bf16x8 g = *reinterpret_cast<const bf16x8*>(p.gate + (long)gm * p.ldg + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = ((float)g[e] > 0.f) ? w[e] * p.gate_scale : 0.f;
+          }
+          if (p.residual) {
+            const bf16x8 rr = *reinterpret_cast<const bf16x8*>(p.residual + orow * p.ldr + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] += (float)rr[e];
+          }
+          *reinterpret_cast<bf16x8*>(p.C + orow * p.ldc + col) = pack8(w);
+        }
+      }
+    }
+  }
+}
+
 template <int BN>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(const GemmParams p) {
   constexpr int WN = BN / 2;        // wave tile columns
@@ -126,73 +209,110 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(const GemmParams 
     }
   }
 
-  const IqRng rng = p.drop_on ? rng_resolve(p.rng) : p.rng;
-  // ---- epilogue: accumulators -> wave-private fp32 strip -> row-contiguous vectors -> HBM ----
-  float* strip = reinterpret_cast<float*>(smem) + wave * (16 * STRIP_LD);
-  constexpr int CPL = WN / 4;       // columns per lane (16 | 8)
-  const int er = lane >> 2, ec = (lane & 3) * CPL;
+  gemm_epilogue<BN>(p, acc, smem, m0, n0, lane, wave);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Fast path (K % 32 == 0): operands stream HBM -> LDS with global_load_lds_dwordx4 (no VGPR staging)
+// through a 3-slot ring, two 32-deep K stages in flight behind the one being multiplied, counted
+// s_waitcnt vmcnt + raw s_barrier (guide 5, "Pipelining across barriers").  The register-staged
+// kernel above keeps one stage in flight and exposes the full HBM latency on every K step
+// (measured 2.0-2.9 TB/s algorithmic on the ViT-Tiny shapes); this one is bounded by bytes.
+// Stage = [128 + BN rows][64 B]; 16 B chunk c of row r sits at chunk c ^ f(r>>2), f = {0,2,3,1} (chosen so
+// that the 16-lane groups of ds_read_b128, which mix lanes of chunk c and c+1, hit 16 distinct slots): the DMA
+// writes LDS lane-linearly, so the swizzle is applied to the per-lane SOURCE address (guide rule 21)
+// and again on the ds_read_b128 fragment reads, which are then bank-conflict free.
+// Rows past M / N are clamped to the last valid row (their products are never stored).
+__device__ __forceinline__ int swz64(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
+
+template <int BN>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmParams p) {
+  constexpr int BK2 = 32;
+  constexpr int WN = BN / 2, NT = WN / 16, MT = 4;
+  constexpr int STAGE_BYTES = (BM + BN) * BK2 * 2;     // 16 KiB | 12 KiB
+  constexpr int NS = 3;
+  constexpr int A_LD = BM * BK2 * 2 / (4 * 1024);      // 1 KiB DMA pieces per wave per stage: A 2
+  constexpr int B_LD = BN * BK2 * 2 / (4 * 1024);      //                                      B 2 | 1
+  constexpr int PER_STAGE = A_LD + B_LD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int t = xcd_remap(blockIdx.x, ntiles);
+  const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
+
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane source rows for this wave's DMA pieces (16 rows x 64 B per piece)
+  const int prow = lane >> 2, pch = lane & 3;
+  const bf16* a_src[A_LD];
+  const bf16* b_src[B_LD];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) strip[((lane >> 4) * 4 + r) * STRIP_LD + j * 16 + (lane & 15)] = acc[i][j][r];
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    float v[CPL];
-#pragma unroll
-    for (int q = 0; q < CPL / 4; ++q) {
-      const f32x4 tq = *reinterpret_cast<const f32x4*>(strip + er * STRIP_LD + ec + q * 4);
-      v[q * 4 + 0] = tq[0]; v[q * 4 + 1] = tq[1]; v[q * 4 + 2] = tq[2]; v[q * 4 + 3] = tq[3];
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int gm = m0 + wm * 64 + i * 16 + er;
-    const int gn = n0 + wn * WN + ec;
-    if (gm < p.M) {
-      long orow = gm;
-      int prow = 0;
-      if (p.tok > 0) {
-        const int f = gm / p.tok, tk = gm - f * p.tok;
-        prow = tk + p.cls_off;
-        orow = (long)f * p.seq + prow;
-      }
-#pragma unroll
-      for (int h = 0; h < CPL / 8; ++h) {
-        const int col = gn + h * 8;
-        if (col < p.N) {
-          float* w = v + h * 8;
-          if (p.bias) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) w[e] += p.bias[col + e];
-          }
-          if (p.relu) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) w[e] = fmaxf(w[e], 0.f);
-          }
-          if (p.pe) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) w[e] += p.pe[(long)prow * p.N + col + e];
-          }
-          if (p.drop_on) {
-            const uint32_t keep = dropout_keep8(rng, (uint64_t)(orow * p.N + col) >> 3, p.thresh);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) w[e] = ((keep >> e) & 1u) ? w[e] * p.dscale : 0.f;
-          }
-          if (p.gate) {
-            const bf16x8 g = *reinterpret_cast<const bf16x8*>(p.gate + (long)gm * p.ldg + col);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) w[e] = ((float)g[e] > 0.f) ? w[e] * p.gate_scale : 0.f;
-          }
-          if (p.residual) {
-            const bf16x8 rr = *reinterpret_cast<const bf16x8*>(p.residual + orow * p.ldr + col);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) w[e] += (float)rr[e];
-          }
-          *reinterpret_cast<bf16x8*>(p.C + orow * p.ldc + col) = pack8(w);
-        }
-      }
-    }
+  for (int i = 0; i < A_LD; ++i) {
+    const int row = (wave * A_LD + i) * 16 + prow;
+    const int gm = min(m0 + row, p.M - 1);
+    a_src[i] = p.A + (long)gm * p.lda + (pch ^ swz64(row)) * 8;
   }
+#pragma unroll
+  for (int i = 0; i < B_LD; ++i) {
+    const int row = (wave * B_LD + i) * 16 + prow;
+    const int gn = min(n0 + row, p.N - 1);
+    b_src[i] = p.B + (long)gn * p.ldb + (pch ^ swz64(row)) * 8;
+  }
+  auto issue = [&](int ks) {
+    unsigned char* st = smem + (ks % NS) * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(a_src[i] + ks * BK2), (lds_void_t*)(st + (wave * A_LD + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(b_src[i] + ks * BK2),
+                                       (lds_void_t*)(st + BM * BK2 * 2 + (wave * B_LD + i) * 1024), 16, 0, 0);
+  };
+
+  const int nk = p.K / BK2;
+  issue(0);
+  if (nk > 1) issue(1);
+  for (int ks = 0; ks < nk; ++ks) {
+    if (ks + 1 < nk) {
+      if (PER_STAGE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();      // stage ks landed for every wave; everyone is done reading stage ks-1
+    asm volatile("" ::: "memory");
+    if (ks + 2 < nk) issue(ks + 2);    // refills the slot stage ks-1 just vacated
+    const bf16* As = reinterpret_cast<const bf16*>(smem + (ks % NS) * STAGE_BYTES);
+    const bf16* Bs = As + BM * BK2;
+    bf16x8 af[MT], bfr[NT];
+    const int ch = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int row = wm * 64 + i * 16 + (lane & 15);
+      af[i] = *reinterpret_cast<const bf16x8*>(As + row * BK2 + (ch ^ swz64(row)) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int row = wn * WN + j * 16 + (lane & 15);
+      bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + row * BK2 + (ch ^ swz64(row)) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+  }
+  __syncthreads();     // all fragment reads retired before the strips overwrite the ring
+  gemm_epilogue<BN>(p, acc, smem, m0, n0, lane, wave);
 }
 
 }  // namespace
@@ -224,14 +344,22 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   hipStream_t st = (hipStream_t)stream;
   IQ_PROF(IQ_FAM_GEMM_NT, st);
   p.tiles_m = (M + BM - 1) / BM;
-  if (N % 128 == 0 || N > 512) {
-    p.tiles_n = (N + 127) / 128;
-    const size_t lds = (size_t)(BM + 128) * BK * 2;
-    gemm_nt_kernel<128><<<p.tiles_m * p.tiles_n, GEMM_THREADS, lds, st>>>(p);
+  const bool wide = (N % 128 == 0 || N > 512);
+  const int bn = wide ? 128 : 64;
+  p.tiles_n = (N + bn - 1) / bn;
+  const int grid = p.tiles_m * p.tiles_n;
+  const bool async_ok = (K % 32 == 0) && (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
+  if (async_ok) {
+    // ring of 3 stages; the epilogue strips (4 x 16 x (bn/2+4) floats) reuse it
+    size_t lds = (size_t)3 * (BM + bn) * 32 * 2;
+    const size_t strips = (size_t)4 * 16 * (bn / 2 + 4) * sizeof(float);
+    if (lds < strips) lds = strips;
+    if (wide) gemm_nt_async_kernel<128><<<grid, GEMM_THREADS, lds, st>>>(p);
+    else gemm_nt_async_kernel<64><<<grid, GEMM_THREADS, lds, st>>>(p);
   } else {
-    p.tiles_n = (N + 63) / 64;
-    const size_t lds = (size_t)(BM + 64) * BK * 2;
-    gemm_nt_kernel<64><<<p.tiles_m * p.tiles_n, GEMM_THREADS, lds, st>>>(p);
+    const size_t lds = (size_t)(BM + bn) * BK * 2;
+    if (wide) gemm_nt_kernel<128><<<grid, GEMM_THREADS, lds, st>>>(p);
+    else gemm_nt_kernel<64><<<grid, GEMM_THREADS, lds, st>>>(p);
   }
   return iq_launch_status();
 }

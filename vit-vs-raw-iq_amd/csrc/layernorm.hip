@@ -210,11 +210,12 @@ inline bool ln_dispatch(const LnShape& s, F&& f) {
   return false;
 }
 
-constexpr int LN_MAX_BLOCKS = 512;
+constexpr int LN_MAX_BLOCKS = 512;      // backward: one partial row per block
+constexpr int LN_FWD_MAX_BLOCKS = 4096;
 
-inline int ln_grid(int M, int rpb) {
+inline int ln_grid(int M, int rpb, int cap = LN_MAX_BLOCKS) {
   long nb = ((long)M + rpb - 1) / rpb;
-  if (nb > LN_MAX_BLOCKS) nb = LN_MAX_BLOCKS;
+  if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;
   return (int)nb;
 }
@@ -237,7 +238,7 @@ extern "C" int iq_ln_fwd(const void* z, const float* gamma, const float* beta, v
   IQ_PROF(IQ_FAM_LN_FWD, st);
   bool ok = ln_dispatch(s, [&](auto lpr, auto nv) {
     constexpr int LPR = decltype(lpr)::value, NV = decltype(nv)::value;
-    ln_fwd_kernel<LPR, NV><<<ln_grid(M, (64 / LPR) * 4), LN_THREADS, 0, st>>>((const bf16*)z, gamma, beta, (bf16*)x, mean,
+    ln_fwd_kernel<LPR, NV><<<ln_grid(M, (64 / LPR) * 4, LN_FWD_MAX_BLOCKS), LN_THREADS, 0, st>>>((const bf16*)z, gamma, beta, (bf16*)x, mean,
                                                                              rstd, M, D, eps);
   });
   return ok ? iq_launch_status() : IQ_ERR_UNSUPPORTED;
