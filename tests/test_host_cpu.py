@@ -1,0 +1,166 @@
+"""CPU: host-side logic and the C-ABI library surface (no compute calls, no GPU)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT, golden_names, load_golden
+
+HEADER = os.path.join(ROOT, "include", "iqvit.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(iq_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    import vit_vs_raw_iq_amd._native as N
+    assert os.path.exists(N.LIB_PATH), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(N.LIB_PATH)
+    names = declared_functions()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/iqvit.h but not exported by libiqvit.so"
+    # and the ctypes binding covers exactly the header
+    assert sorted(N.SIGNATURES) == names
+    N.lib()
+
+
+def test_struct_layouts_match_the_header_field_order():
+    import vit_vs_raw_iq_amd._native as N
+    src = open(HEADER).read()
+
+    def fields(struct):
+        body = re.search(r"typedef struct %s \{(.*?)\}" % struct, src, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                out.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", part)[-1])
+        return out
+
+    assert fields("iq_dropout") == [f[0] for f in N.Dropout._fields_]
+    assert fields("iq_epilogue") == [f[0] for f in N.Epilogue._fields_]
+    assert fields("iq_model_cfg") == [f[0] for f in N.ModelCfg._fields_]
+
+
+def test_host_only_queries_work_without_a_gpu():
+    """Pure host functions of the ABI (layout / planning) are callable on CPU."""
+    import vit_vs_raw_iq_amd._native as N
+    L = N.lib()
+    assert L.iq_ln_supported(192) == 1 and L.iq_ln_supported(20) == 0
+    assert L.iq_attn_supported(197, 64) == 1 and L.iq_attn_supported(2000, 64) == 0
+    assert L.iq_wgrad_ws_bytes(50432, 768, 192) > 0
+    cfg = N.ModelCfg(kind=0, in_channels=1, img_h=224, img_w=224, patch=16, seq_length=0, conv_k=0, use_cls=1,
+                     num_classes=19, d_model=192, n_head=3, n_layers=12, ffn_hidden=768, drop_prob=0.1)
+    h = ctypes.c_void_p()
+    assert L.iq_model_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
+    assert L.iq_model_tokens(h) == 197
+    # parameter entries cover exactly the reference's parameter count (5,391,571)
+    total = 0
+    name = ctypes.create_string_buffer(256)
+    off, nd, dims = ctypes.c_size_t(), ctypes.c_int(), (ctypes.c_int * 4)()
+    offs = []
+    for i in range(L.iq_model_param_entries(h)):
+        assert L.iq_model_param_entry(h, i, name, 256, ctypes.byref(off), ctypes.byref(nd), dims) == 0
+        n = 1
+        for k in range(nd.value):
+            n *= dims[k]
+        total += n
+        offs.append((off.value, n))
+        assert off.value % 8 == 0
+    assert total == 5391571
+    offs.sort()
+    for (o1, n1), (o2, _) in zip(offs, offs[1:]):
+        assert o1 + n1 <= o2, "parameter entries overlap"
+    assert L.iq_model_param_floats(h) >= offs[-1][0] + offs[-1][1]
+    # stage ranges tile the flat gradient: embedding | layers | head
+    o, ln = ctypes.c_size_t(), ctypes.c_size_t()
+    pos = 0
+    for s in range(0, 14):
+        assert L.iq_model_grad_range(h, s, s, ctypes.byref(o), ctypes.byref(ln)) == 0
+        assert o.value == pos
+        pos += ln.value
+    assert pos == L.iq_model_param_floats(h)
+    assert L.iq_model_workspace_bytes(h, 256, 1) > 256 * 197 * 192 * 2 * 12 * 8
+    L.iq_model_destroy(h)
+    bad = N.ModelCfg(kind=0, in_channels=1, img_h=32, img_w=32, patch=16, seq_length=0, conv_k=0, use_cls=1,
+                     num_classes=3, d_model=100, n_head=4, n_layers=1, ffn_hidden=64, drop_prob=0.0)
+    assert L.iq_model_create(ctypes.byref(bad), ctypes.byref(h)) != 0      # head dim 25: refused, not emulated
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_module_surface_matches_reference_state_dict(name):
+    """Constructor kwargs, state_dict keys/shapes and seeded initial values (CPU construction only)."""
+    import numpy as np
+    import vit_vs_raw_iq_amd as P
+    import iq_oracle as O
+    kind, kw, z = load_golden(name)
+    torch.manual_seed(int(z["seed"]))
+    m = (P.AMCTransformerViT if kind == "vit" else P.AMCTransformerRawIQ)(drop_prob=0.0, device="cpu", **kw)
+    sd = O.init_state(O.OracleConfig(kind=kind, drop_prob=0.0, **kw), int(z["seed"]))
+    got = m.state_dict()
+    assert list(sorted(got)) == list(sorted(sd))
+    for k in sd:
+        assert torch.equal(got[k], sd[k]), k
+    assert np.array_equal(got["encoder.positional_encoding.encoding"].numpy(), z["pe"])
+    assert sum(p.numel() for p in m.parameters()) == int(z["n_params"])
+
+
+def test_reference_import_paths_and_error_conventions():
+    from vit_vs_raw_iq_amd.ViT.models.amc_transformer import AMCTransformer as V
+    from vit_vs_raw_iq_amd.transformer_rawIQ.models.transformer_rawIQ import AMCTransformer as R
+    import vit_vs_raw_iq_amd as P
+    assert V is P.AMCTransformerViT and R is P.AMCTransformerRawIQ
+    # hyperparameter_tuning.py:22-34 / :41-54 call surfaces
+    V(in_channels=1, img_size_h=32, img_size_w=32, patch_size=16, num_classes=11, d_model=128, n_head=8, n_layers=1,
+      ffn_hidden=256, drop_prob=0.1, device="cpu")
+    r = R(in_channels=2, seq_length=1024, num_classes=11, d_model=128, n_head=8, n_layers=1, ffn_hidden=256,
+          drop_prob=0.1, device="cpu", use_cls_token=True, embedding_type="segment", segment_size=64)
+    with pytest.raises(ValueError, match=r"seq_length \(1000\) must be divisible by segment_size \(64\)"):
+        R(in_channels=2, seq_length=1000, num_classes=3, d_model=64, n_head=4, n_layers=1, ffn_hidden=64,
+          drop_prob=0.0, device="cpu", segment_size=64)
+    with pytest.raises(ValueError, match="Unknown embedding_type: patch"):
+        R(in_channels=2, seq_length=1024, num_classes=3, d_model=64, n_head=4, n_layers=1, ffn_hidden=64,
+          drop_prob=0.0, device="cpu", embedding_type="patch")
+    with pytest.raises(ValueError, match="segment_size is required"):
+        P.SequenceEmbedding(method="segment")
+    with pytest.raises(ValueError, match="Unknown method"):
+        P.SequenceEmbedding(method="foo")
+    # the product path never computes on CPU
+    with pytest.raises(P.IqError, match="no CPU fallback"):
+        r(torch.zeros(1, 2, 1024))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "vit-vs-raw-iq_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "iq_oracle" not in text and "import oracle" not in text, os.path.join(dirpath, f)
+    code = ("import sys; sys.path.insert(0, %r); import vit_vs_raw_iq_amd, vit_vs_raw_iq_amd.trainer; "
+            "assert 'iq_oracle' not in sys.modules" % ROOT)
+    subprocess.check_call([sys.executable, "-c", code])
+
+
+def test_bucket_plan_covers_every_stage_once():
+    from vit_vs_raw_iq_amd.trainer import make_buckets
+    for L_ in (0, 1, 2, 6, 12):
+        for nb in (1, 2, 3, 4, 7, 50):
+            b = make_buckets(L_, nb)
+            stages = []
+            for hi, lo in b:
+                assert hi >= lo
+                stages += list(range(hi, lo - 1, -1))
+            assert stages == list(range(L_ + 1, -1, -1))

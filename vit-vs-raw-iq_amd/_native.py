@@ -78,6 +78,8 @@ SIGNATURES = {
     "iq_model_forward": (_I, [_P, _P, _I, _P, _Z, _I, _U64, _U32, _P, _P, _P]),
     "iq_model_backward": (_I, [_P, _P, _P, _I, _P, _Z, _I, _I, _I, _P]),
     "iq_model_grad_range": (_I, [_P, _I, _I, C.POINTER(_Z), C.POINTER(_Z)]),
+    "iq_prof_enable": (_I, [_I]),
+    "iq_prof_collect": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 }
 
 _lib = None

@@ -173,21 +173,21 @@ class FusedTrainer:
         self._buffers(B)
         if self.use_graph:
             if self._graph is None:
+                # first call: one eager step on static buffers (this call's step; also warms lazy kernel
+                # attributes and the allocator), then capture the identical launch sequence for later replays
                 self._static = (torch.empty_like(x), torch.empty_like(y))
                 self._static[0].copy_(x)
                 self._static[1].copy_(y)
-                # one eager step first (lazy kernel-attribute setup, allocator warm-up), then capture
                 self._launch(self._static[0], self._static[1], auto_step=True)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._launch(self._static[0], self._static[1], auto_step=True)
                 self._graph = g
-                self.steps += 1
-                self.frames_seen += B
-            self._static[0].copy_(x, non_blocking=True)
-            self._static[1].copy_(y, non_blocking=True)
-            self._graph.replay()
+            else:
+                self._static[0].copy_(x, non_blocking=True)
+                self._static[1].copy_(y, non_blocking=True)
+                self._graph.replay()
         else:
             self._launch(x, y, auto_step=False)
         self.steps += 1
