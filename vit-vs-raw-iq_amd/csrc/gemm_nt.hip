@@ -14,8 +14,8 @@
 // Tile: 128 x BN (BN = 128 | 64), BK = 64, 4 waves (2x2), mfma_f32_16x16x32_bf16.
 // LDS tile rows are 128 B; 16 B chunk c of row r lives at chunk c ^ ((r>>1)&7), which makes the
 // ds_read_b128 fragment reads (16 rows x one chunk column per lane group) bank-conflict free.
-// Epilogue: each wave stages 16-row strips of its accumulators through a private fp32 LDS strip
-// so that a lane owns 8..16 consecutive columns of one row.
+// Epilogue: register-only (see gemm_epilogue): C^T accumulators + v_permlane16_swap give each lane 8
+// consecutive columns of a row.
 #include "common.h"
 #include "iqvit.h"
 #include "prof.h"
@@ -25,6 +25,9 @@ namespace {
 constexpr int BM = 128, BK = 64, GEMM_THREADS = 256;
 
 struct GemmParams {
+#ifdef IQ_GEMM_STAMPS
+  unsigned long long* stamps;   // diagnostic build: [grid][6] s_memtime values
+#endif
   const bf16* A; const bf16* B; bf16* C;
   int lda, ldb, ldc, M, N, K;
   const float* bias; int relu;
@@ -37,97 +40,127 @@ struct GemmParams {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-// Epilogue shared by both kernels: accumulators -> wave-private fp32 LDS strip -> one lane owns 8..16
-// consecutive columns of a row -> fused bias / ReLU / PE / dropout / gate / residual -> 16 B bf16 stores.
-// The caller guarantees no LDS tile reads or DMA writes are outstanding.
-template <int BN>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][BN / 32], unsigned char* smem, int m0,
-                                              int n0, int lane, int wave) {
+// Epilogue shared by both kernels -- registers only, no LDS round trip.
+// The MFMAs are issued with the WEIGHT fragment as the A operand, so an accumulator tile is C^T:
+// lane (g = lane>>4, c = lane&15) holds C[row = 16i + c][cols 16j + 4g .. 4g+3].  One
+// v_permlane16_swap per register between the two tiles of a column pair (2jp, 2jp+1) leaves every lane
+// with EIGHT consecutive columns of one row (even g: tile 2jp, cols 4g..4g+7; odd g: tile 2jp+1, cols
+// 4(g-1)..4(g-1)+7): one 16 B bf16 store per lane, a wave instruction covers 16 rows x 64 B, and the
+// 8-column group is exactly the Philox dropout group, so the whole elementwise tail (bias, ReLU, PE,
+// dropout, gate, residual) runs lane-locally on fp32 before the single rounding to bf16.
+// (The first version staged fp32 strips through LDS: 45-55 % of a workgroup's life was this epilogue.)
+// EPI bit 0: residual, bit 1: gate, bit 2: positional table (+ row remap).  Compile-time so that each
+// variant is straight-line: every global LOAD of the tail (bias, residual, gate) is issued up front and
+// retired by ONE counted wait, and the store loop then contains no vmcnt wait at all.  (CDNA counts
+// loads and stores in one in-order vmcnt: a load waited for after a store also waits for that store, and
+// the runtime-flag version of this loop serialised its 8 stores on the full write latency -- 8.2k of the
+// 18k cycles a workgroup lived.)
+constexpr int EPI_RES = 1, EPI_GATE = 2, EPI_PE = 4;
+
+template <int BN, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][BN / 32], int m0, int n0, int lane,
+                                              int wave) {
   constexpr int WN = BN / 2;
   constexpr int NT = WN / 16;
+  constexpr int NP = NT / 2;       // column-tile pairs
   constexpr int MT = 4;
-  constexpr int STRIP_LD = WN + 4;
   const int wm = wave >> 1, wn = wave & 1;
+  const int g = lane >> 4, c16 = lane & 15;
+  const bool odd = (g & 1) != 0;
   const IqRng rng = p.drop_on ? rng_resolve(p.rng) : p.rng;
-  float* strip = reinterpret_cast<float*>(smem) + wave * (16 * STRIP_LD);
-  constexpr int CPL = WN / 4;       // columns per lane (16 | 8)
-  const int er = lane >> 2, ec = (lane & 3) * CPL;
-  float bias_r[CPL];                // the lane's columns are the same for every strip: load the bias once
-#pragma unroll
-  for (int e = 0; e < CPL; ++e) {
-    const int col = n0 + wn * WN + ec + e;
-    bias_r[e] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
-  }
+  int colp[NP];
+  f32x4 bias_lo[NP], bias_hi[NP];
+  long orow[MT];
+  int prow[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) strip[((lane >> 4) * 4 + r) * STRIP_LD + j * 16 + (lane & 15)] = acc[i][j][r];
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    float v[CPL];
-#pragma unroll
-    for (int q = 0; q < CPL / 4; ++q) {
-      const f32x4 tq = *reinterpret_cast<const f32x4*>(strip + er * STRIP_LD + ec + q * 4);
-      v[q * 4 + 0] = tq[0]; v[q * 4 + 1] = tq[1]; v[q * 4 + 2] = tq[2]; v[q * 4 + 3] = tq[3];
+    const int gm = m0 + wm * 64 + i * 16 + c16;
+    orow[i] = gm;
+    prow[i] = 0;
+    if (EPI & EPI_PE) {
+      const int f = gm / p.tok, tk = gm - f * p.tok;
+      prow[i] = tk + p.cls_off;
+      orow[i] = (long)f * p.seq + prow[i];
     }
-    __builtin_amdgcn_wave_barrier();
-    const int gm = m0 + wm * 64 + i * 16 + er;
-    const int gn = n0 + wn * WN + ec;
-    if (gm < p.M) {
-      long orow = gm;
-      int prow = 0;
-      if (p.tok > 0) {
-        const int f = gm / p.tok, tk = gm - f * p.tok;
-        prow = tk + p.cls_off;
-        orow = (long)f * p.seq + prow;
+  }
+  bf16x8 res[(EPI & EPI_RES) ? MT : 1][NP], gt[(EPI & EPI_GATE) ? MT : 1][NP];
+#pragma unroll
+  for (int jp = 0; jp < NP; ++jp) {
+    colp[jp] = n0 + wn * WN + (odd ? (2 * jp + 1) * 16 + 4 * (g - 1) : (2 * jp) * 16 + 4 * g);
+    bias_lo[jp] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bias_hi[jp] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias && colp[jp] < p.N) {
+      bias_lo[jp] = *reinterpret_cast<const f32x4*>(p.bias + colp[jp]);
+      bias_hi[jp] = *reinterpret_cast<const f32x4*>(p.bias + colp[jp] + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int gm = m0 + wm * 64 + i * 16 + c16;
+      const bool ok = gm < p.M && colp[jp] < p.N;
+      if (EPI & EPI_RES) {
+        res[i][jp] = bf16x8{};
+        if (ok) res[i][jp] = *reinterpret_cast<const bf16x8*>(p.residual + orow[i] * p.ldr + colp[jp]);
       }
+      if (EPI & EPI_GATE) {
+        gt[i][jp] = bf16x8{};
+        if (ok) gt[i][jp] = *reinterpret_cast<const bf16x8*>(p.gate + (long)gm * p.ldg + colp[jp]);
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): every load above has landed; none below (PE variant excepted)
 #pragma unroll
-      for (int h = 0; h < CPL / 8; ++h) {
-        const int col = gn + h * 8;
-        if (col < p.N) {
-          float* w = v + h * 8;
+  for (int i = 0; i < MT; ++i) {
+    const int gm = m0 + wm * 64 + i * 16 + c16;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) w[e] += bias_r[h * 8 + e];
-          if (p.relu) {
+    for (int jp = 0; jp < NP; ++jp) {
+      float w[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) w[e] = fmaxf(w[e], 0.f);
-          }
-          if (p.pe) {
+      for (int r = 0; r < 4; ++r) {
+        // (copy the vector elements to scalars first: bit-casting an ext-vector element lvalue made clang
+        //  read element 0 for every r)
+        const float va = acc[i][2 * jp][r], vb = acc[i][2 * jp + 1][r];
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
+        w[r] = __uint_as_float(sw[0]) + bias_lo[jp][r];
+        w[4 + r] = __uint_as_float(sw[1]) + bias_hi[jp][r];
+      }
+      const int col = colp[jp];
+      if (gm < p.M && col < p.N) {
+        if (p.relu) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) w[e] += p.pe[(long)prow * p.N + col + e];
-          }
-          if (p.drop_on) {
-            const uint32_t keep = dropout_keep8(rng, (uint64_t)(orow * p.N + col) >> 3, p.thresh);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) w[e] = ((keep >> e) & 1u) ? w[e] * p.dscale : 0.f;
-          }
-          if (p.gate) {
-            const bf16x8 g = *reinterpret_cast<const bf16x8*>(p.gate + (long)gm * p.ldg + col);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) w[e] = ((float)g[e] > 0.f) ? w[e] * p.gate_scale : 0.f;
-          }
-          if (p.residual) {
-            const bf16x8 rr = *reinterpret_cast<const bf16x8*>(p.residual + orow * p.ldr + col);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) w[e] += (float)rr[e];
-          }
-          *reinterpret_cast<bf16x8*>(p.C + orow * p.ldc + col) = pack8(w);
+          for (int e = 0; e < 8; ++e) w[e] = fmaxf(w[e], 0.f);
         }
+        if (EPI & EPI_PE) {
+          const f32x4 pa = *reinterpret_cast<const f32x4*>(p.pe + (long)prow[i] * p.N + col);
+          const f32x4 pb = *reinterpret_cast<const f32x4*>(p.pe + (long)prow[i] * p.N + col + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { w[e] += pa[e]; w[4 + e] += pb[e]; }
+        }
+        if (p.drop_on) {
+          const uint32_t keep = dropout_keep8(rng, (uint64_t)(orow[i] * p.N + col) >> 3, p.thresh);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = ((keep >> e) & 1u) ? w[e] * p.dscale : 0.f;
+        }
+        if (EPI & EPI_GATE) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = ((float)gt[i][jp][e] > 0.f) ? w[e] * p.gate_scale : 0.f;
+        }
+        if (EPI & EPI_RES) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] += (float)res[i][jp][e];
+        }
+        *reinterpret_cast<bf16x8*>(p.C + orow[i] * p.ldc + col) = pack8(w);
       }
     }
   }
 }
 
-template <int BN>
+template <int BN, int EPI>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(const GemmParams p) {
   constexpr int WN = BN / 2;        // wave tile columns
   constexpr int NT = WN / 16;       // 16-col MFMA tiles per wave
   constexpr int MT = 4;             // 16-row MFMA tiles per wave (wave tile rows = 64)
   constexpr int A_CH = BM * 8 / GEMM_THREADS;  // 16 B chunks per thread
   constexpr int B_CH = BN * 8 / GEMM_THREADS;
-  constexpr int STRIP_LD = WN + 4;  // floats
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16* As = reinterpret_cast<bf16*>(smem);                 // [BM][64]
   bf16* Bs = reinterpret_cast<bf16*>(smem + BM * BK * 2);   // [BN][64]
@@ -200,7 +233,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(const GemmParams 
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile: see gemm_epilogue
     }
     __syncthreads();
     if (kt + 1 < nk) {
@@ -209,7 +242,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(const GemmParams 
     }
   }
 
-  gemm_epilogue<BN>(p, acc, smem, m0, n0, lane, wave);
+  gemm_epilogue<BN, EPI>(p, acc, m0, n0, lane, wave);
 }
 
 
@@ -228,7 +261,7 @@ __device__ __forceinline__ int swz64(int row) { return (0x78 >> (((row >> 2) & 3
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 
-template <int BN>
+template <int BN, int EPI>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmParams p) {
   constexpr int BK2 = 32;
   constexpr int WN = BN / 2, NT = WN / 16, MT = 4;
@@ -278,6 +311,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
                                        (lds_void_t*)(st + BM * BK2 * 2 + (wave * B_LD + i) * 1024), 16, 0, 0);
   };
 
+#ifdef IQ_GEMM_STAMPS
+#define IQ_STAMP(i) do { if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.stamps[(long)blockIdx.x * 6 + (i)] = t_; } } while (0)
+#else
+#define IQ_STAMP(i) do {} while (0)
+#endif
+  IQ_STAMP(0);
   const int nk = p.K / BK2;
   issue(0);
   if (nk > 1) issue(1);
@@ -290,6 +329,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
     }
     __builtin_amdgcn_s_barrier();      // stage ks landed for every wave; everyone is done reading stage ks-1
     asm volatile("" ::: "memory");
+    if (ks == 0) IQ_STAMP(1);
     if (ks + 2 < nk) issue(ks + 2);    // refills the slot stage ks-1 just vacated
     const bf16* As = reinterpret_cast<const bf16*>(smem + (ks % NS) * STAGE_BYTES);
     const bf16* Bs = As + BM * BK2;
@@ -309,14 +349,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile: see gemm_epilogue
   }
-  __syncthreads();     // all fragment reads retired before the strips overwrite the ring
-  gemm_epilogue<BN>(p, acc, smem, m0, n0, lane, wave);
+  IQ_STAMP(2);
+  IQ_STAMP(3);
+  gemm_epilogue<BN, EPI>(p, acc, m0, n0, lane, wave);
+  IQ_STAMP(4);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  IQ_STAMP(5);
 }
 
 }  // namespace
 
+#ifdef IQ_GEMM_STAMPS
+static unsigned long long* g_stamps = nullptr;
+extern "C" void iq_debug_set_stamps(unsigned long long* p) { g_stamps = p; }
+#endif
 extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                                const iq_epilogue_t* epi, iq_stream_t stream) {
   if (M <= 0 || N <= 0) return IQ_OK;
@@ -325,6 +373,9 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   GemmParams p = {};
   p.A = (const bf16*)A; p.B = (const bf16*)B; p.C = (bf16*)C;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+#ifdef IQ_GEMM_STAMPS
+  p.stamps = g_stamps;
+#endif
   if (epi) {
     p.bias = epi->bias; p.relu = epi->relu;
     p.pe = epi->pe; p.tok = epi->tok; p.seq = epi->seq; p.cls_off = epi->cls_off;
@@ -349,17 +400,27 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   p.tiles_n = (N + bn - 1) / bn;
   const int grid = p.tiles_m * p.tiles_n;
   const bool async_ok = (K % 32 == 0) && (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
-  if (async_ok) {
-    // ring of 3 stages; the epilogue strips (4 x 16 x (bn/2+4) floats) reuse it
-    size_t lds = (size_t)3 * (BM + bn) * 32 * 2;
-    const size_t strips = (size_t)4 * 16 * (bn / 2 + 4) * sizeof(float);
-    if (lds < strips) lds = strips;
-    if (wide) gemm_nt_async_kernel<128><<<grid, GEMM_THREADS, lds, st>>>(p);
-    else gemm_nt_async_kernel<64><<<grid, GEMM_THREADS, lds, st>>>(p);
-  } else {
-    const size_t lds = (size_t)(BM + bn) * BK * 2;
-    if (wide) gemm_nt_kernel<128><<<grid, GEMM_THREADS, lds, st>>>(p);
-    else gemm_nt_kernel<64><<<grid, GEMM_THREADS, lds, st>>>(p);
+  int epi_mode = (p.residual ? EPI_RES : 0) | (p.gate ? EPI_GATE : 0) | ((p.pe || p.tok > 0) ? EPI_PE : 0);
+  if ((epi_mode & EPI_PE) && (!p.pe || p.tok <= 0 || (epi_mode & (EPI_RES | EPI_GATE)))) return IQ_ERR_UNSUPPORTED;
+  if (p.bias && ((uintptr_t)p.bias % 16)) return IQ_ERR_ARG;
+  const size_t lds_async = (size_t)3 * (BM + bn) * 32 * 2;     // ring of 3 stages
+  const size_t lds_reg = (size_t)(BM + bn) * BK * 2;
+#define IQ_GEMM_LAUNCH(BN_, EPI_)                                                                  \
+  do {                                                                                             \
+    if (async_ok) gemm_nt_async_kernel<BN_, EPI_><<<grid, GEMM_THREADS, lds_async, st>>>(p);       \
+    else gemm_nt_kernel<BN_, EPI_><<<grid, GEMM_THREADS, lds_reg, st>>>(p);                        \
+  } while (0)
+#define IQ_GEMM_EPI(BN_)                                                       \
+  switch (epi_mode) {                                                          \
+    case 0: IQ_GEMM_LAUNCH(BN_, 0); break;                                     \
+    case EPI_RES: IQ_GEMM_LAUNCH(BN_, EPI_RES); break;                         \
+    case EPI_GATE: IQ_GEMM_LAUNCH(BN_, EPI_GATE); break;                       \
+    case EPI_RES | EPI_GATE: IQ_GEMM_LAUNCH(BN_, EPI_RES | EPI_GATE); break;   \
+    case EPI_PE: IQ_GEMM_LAUNCH(BN_, EPI_PE); break;                           \
+    default: return IQ_ERR_UNSUPPORTED;                                        \
   }
+  if (wide) { IQ_GEMM_EPI(128) } else { IQ_GEMM_EPI(64) }
+#undef IQ_GEMM_EPI
+#undef IQ_GEMM_LAUNCH
   return iq_launch_status();
 }
