@@ -16,6 +16,8 @@
 // ds_read_b128 fragment reads (16 rows x one chunk column per lane group) bank-conflict free.
 // Epilogue: register-only (see gemm_epilogue): C^T accumulators + v_permlane16_swap give each lane 8
 // consecutive columns of a row.
+#include <stdlib.h>
+
 #include "common.h"
 #include "iqvit.h"
 #include "prof.h"
@@ -399,7 +401,8 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   const int bn = wide ? 128 : 64;
   p.tiles_n = (N + bn - 1) / bn;
   const int grid = p.tiles_m * p.tiles_n;
-  const bool async_ok = (K % 32 == 0) && (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
+  static const bool force_reg = getenv("IQ_GEMM_FORCE_REG") != nullptr;   // diagnostics: register-staged path
+  const bool async_ok = !force_reg && (K % 32 == 0) && (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
   int epi_mode = (p.residual ? EPI_RES : 0) | (p.gate ? EPI_GATE : 0) | ((p.pe || p.tok > 0) ? EPI_PE : 0);
   if ((epi_mode & EPI_PE) && (!p.pe || p.tok <= 0 || (epi_mode & (EPI_RES | EPI_GATE)))) return IQ_ERR_UNSUPPORTED;
   if (p.bias && ((uintptr_t)p.bias % 16)) return IQ_ERR_ARG;

@@ -26,7 +26,6 @@ namespace {
 constexpr int WG_THREADS = 512;   // 8 waves: 2 (n) x 4 (k)
 constexpr int TN = 128;           // output rows (n) per tile
 constexpr int MC = 32;            // contraction rows per stage (one MFMA k-step)
-constexpr int NS = 4;             // LDS ring slots: three stages in flight behind the one being multiplied
 
 struct WgradParams {
   const bf16* Y; const bf16* X;
@@ -59,6 +58,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int r0, int
 
 template <int TK>
 __global__ __launch_bounds__(WG_THREADS, 4) void wgrad_kernel(const WgradParams p) {
+  // LDS ring depth: the loop is bounded by bytes in flight per CU (L2/HBM latency x fill rate), so use all the
+  // LDS two workgroups can share: 6 x 12 KiB (TK=64) or 4 x 16 KiB (TK=128) per workgroup.
+  constexpr int NS = TK == 64 ? 6 : 4;
   constexpr int KT = TK / 64;               // 16-col k tiles per wave (wave tile = 64 n x TK/4 k)
   constexpr int YB = TN * 2, XB = TK * 2;   // row bytes
   constexpr int Y_STAGE = MC * YB;          // 8 KiB
@@ -115,14 +117,15 @@ __global__ __launch_bounds__(WG_THREADS, 4) void wgrad_kernel(const WgradParams 
     if (s < ns) issue(s);
   for (int s = 0; s < ns; ++s) {
     const int younger = min(NS - 2, ns - 1 - s);      // stages issued after stage s and still allowed in flight
-    if (x_owner) {
-      if (younger >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      if (younger >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else if (younger == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int outstanding = younger * (x_owner ? 2 : 1);
+    switch (outstanding) {                            // s_waitcnt takes an immediate
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
     __builtin_amdgcn_s_barrier();        // stage s landed everywhere; everyone finished reading stage s-1
     asm volatile("" ::: "memory");
@@ -205,7 +208,9 @@ inline WgradPlan wgrad_plan(int M, int N, int K) {
   w.tiles_n = (N + TN - 1) / TN;
   w.tiles_k = (K + w.tk - 1) / w.tk;
   const int tiles = w.tiles_n * w.tiles_k;
-  int splits = (512 + tiles - 1) / tiles;
+  // Two 8-wave workgroups fit a CU: fill the 512 slots ONCE.  One workgroup more than 512 costs a whole
+  // extra round (522 WGs ran 1.5x slower than 504 on the N=768,K=192 shape).
+  int splits = 512 / tiles;
   const int max_splits = (M + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -245,11 +250,12 @@ extern "C" int iq_gemm_bf16_wgrad(const void* dY, int ldy, const void* X, int ld
   // slab stride must equal N*K for the reduce kernel; nk padding only affects the bias slab offset
   WgradParams q = p;
   if (w.tk == 128) {
-    const size_t lds = (size_t)NS * MC * (TN + 128) * 2;
+    const size_t lds = (size_t)4 * MC * (TN + 128) * 2;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)wgrad_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     wgrad_kernel<128><<<grid, WG_THREADS, lds, st>>>(q);
   } else {
-    const size_t lds = (size_t)NS * MC * (TN + 64) * 2;
+    const size_t lds = (size_t)6 * MC * (TN + 64) * 2;
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     wgrad_kernel<64><<<grid, WG_THREADS, lds, st>>>(q);
   }
   const long n = (long)N * K;
