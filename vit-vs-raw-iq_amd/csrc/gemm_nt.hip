@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gemm_common.h"
 #include "iqvit.h"
 #include "prof.h"
 
@@ -26,135 +27,8 @@ namespace {
 
 constexpr int BM = 128, BK = 64, GEMM_THREADS = 256;
 
-struct GemmParams {
-#ifdef IQ_GEMM_STAMPS
-  unsigned long long* stamps;   // diagnostic build: [grid][6] s_memtime values
-#endif
-  const bf16* A; const bf16* B; bf16* C;
-  int lda, ldb, ldc, M, N, K;
-  const float* bias; int relu;
-  const float* pe; int tok, seq, cls_off;
-  int drop_on; IqRng rng; uint32_t thresh; float dscale;
-  const bf16* gate; int ldg; float gate_scale;
-  const bf16* residual; int ldr;
-  int tiles_m, tiles_n;
-};
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
-
-// Epilogue shared by both kernels -- registers only, no LDS round trip.
-// The MFMAs are issued with the WEIGHT fragment as the A operand, so an accumulator tile is C^T:
-// lane (g = lane>>4, c = lane&15) holds C[row = 16i + c][cols 16j + 4g .. 4g+3].  One
-// v_permlane16_swap per register between the two tiles of a column pair (2jp, 2jp+1) leaves every lane
-// with EIGHT consecutive columns of one row (even g: tile 2jp, cols 4g..4g+7; odd g: tile 2jp+1, cols
-// 4(g-1)..4(g-1)+7): one 16 B bf16 store per lane, a wave instruction covers 16 rows x 64 B, and the
-// 8-column group is exactly the Philox dropout group, so the whole elementwise tail (bias, ReLU, PE,
-// dropout, gate, residual) runs lane-locally on fp32 before the single rounding to bf16.
-// (The first version staged fp32 strips through LDS: 45-55 % of a workgroup's life was this epilogue.)
-// EPI bit 0: residual, bit 1: gate, bit 2: positional table (+ row remap).  Compile-time so that each
-// variant is straight-line: every global LOAD of the tail (bias, residual, gate) is issued up front and
-// retired by ONE counted wait, and the store loop then contains no vmcnt wait at all.  (CDNA counts
-// loads and stores in one in-order vmcnt: a load waited for after a store also waits for that store, and
-// the runtime-flag version of this loop serialised its 8 stores on the full write latency -- 8.2k of the
-// 18k cycles a workgroup lived.)
-constexpr int EPI_RES = 1, EPI_GATE = 2, EPI_PE = 4;
-
-template <int BN, int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][BN / 32], int m0, int n0, int lane,
-                                              int wave) {
-  constexpr int WN = BN / 2;
-  constexpr int NT = WN / 16;
-  constexpr int NP = NT / 2;       // column-tile pairs
-  constexpr int MT = 4;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int g = lane >> 4, c16 = lane & 15;
-  const bool odd = (g & 1) != 0;
-  const IqRng rng = p.drop_on ? rng_resolve(p.rng) : p.rng;
-  int colp[NP];
-  f32x4 bias_lo[NP], bias_hi[NP];
-  long orow[MT];
-  int prow[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int gm = m0 + wm * 64 + i * 16 + c16;
-    orow[i] = gm;
-    prow[i] = 0;
-    if (EPI & EPI_PE) {
-      const int f = gm / p.tok, tk = gm - f * p.tok;
-      prow[i] = tk + p.cls_off;
-      orow[i] = (long)f * p.seq + prow[i];
-    }
-  }
-  bf16x8 res[(EPI & EPI_RES) ? MT : 1][NP], gt[(EPI & EPI_GATE) ? MT : 1][NP];
-#pragma unroll
-  for (int jp = 0; jp < NP; ++jp) {
-    colp[jp] = n0 + wn * WN + (odd ? (2 * jp + 1) * 16 + 4 * (g - 1) : (2 * jp) * 16 + 4 * g);
-    bias_lo[jp] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bias_hi[jp] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias && colp[jp] < p.N) {
-      bias_lo[jp] = *reinterpret_cast<const f32x4*>(p.bias + colp[jp]);
-      bias_hi[jp] = *reinterpret_cast<const f32x4*>(p.bias + colp[jp] + 4);
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int gm = m0 + wm * 64 + i * 16 + c16;
-      const bool ok = gm < p.M && colp[jp] < p.N;
-      if (EPI & EPI_RES) {
-        res[i][jp] = bf16x8{};
-        if (ok) res[i][jp] = *reinterpret_cast<const bf16x8*>(p.residual + orow[i] * p.ldr + colp[jp]);
-      }
-      if (EPI & EPI_GATE) {
-        gt[i][jp] = bf16x8{};
-        if (ok) gt[i][jp] = *reinterpret_cast<const bf16x8*>(p.gate + (long)gm * p.ldg + colp[jp]);
-      }
-    }
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): every load above has landed; none below (PE variant excepted)
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int gm = m0 + wm * 64 + i * 16 + c16;
-#pragma unroll
-    for (int jp = 0; jp < NP; ++jp) {
-      float w[8];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        // (copy the vector elements to scalars first: bit-casting an ext-vector element lvalue made clang
-        //  read element 0 for every r)
-        const float va = acc[i][2 * jp][r], vb = acc[i][2 * jp + 1][r];
-        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
-        w[r] = __uint_as_float(sw[0]) + bias_lo[jp][r];
-        w[4 + r] = __uint_as_float(sw[1]) + bias_hi[jp][r];
-      }
-      const int col = colp[jp];
-      if (gm < p.M && col < p.N) {
-        if (p.relu) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) w[e] = fmaxf(w[e], 0.f);
-        }
-        if (EPI & EPI_PE) {
-          const f32x4 pa = *reinterpret_cast<const f32x4*>(p.pe + (long)prow[i] * p.N + col);
-          const f32x4 pb = *reinterpret_cast<const f32x4*>(p.pe + (long)prow[i] * p.N + col + 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { w[e] += pa[e]; w[4 + e] += pb[e]; }
-        }
-        if (p.drop_on) {
-          const uint32_t keep = dropout_keep8(rng, (uint64_t)(orow[i] * p.N + col) >> 3, p.thresh);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) w[e] = ((keep >> e) & 1u) ? w[e] * p.dscale : 0.f;
-        }
-        if (EPI & EPI_GATE) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) w[e] = ((float)gt[i][jp][e] > 0.f) ? w[e] * p.gate_scale : 0.f;
-        }
-        if (EPI & EPI_RES) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) w[e] += (float)res[i][jp][e];
-        }
-        *reinterpret_cast<bf16x8*>(p.C + orow[i] * p.ldc + col) = pack8(w);
-      }
-    }
-  }
-}
 
 template <int BN, int EPI>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(const GemmParams p) {
@@ -244,7 +118,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(const GemmParams 
     }
   }
 
-  gemm_epilogue<BN, EPI>(p, acc, m0, n0, lane, wave);
+  gemm_epilogue<4, BN / 32, EPI>(p, acc, m0 + (wave >> 1) * 64, n0 + (wave & 1) * (BN / 2), lane);
 }
 
 
@@ -318,6 +192,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
 #else
 #define IQ_STAMP(i) do {} while (0)
 #endif
+  if (p.stagger > 0) {
+    // Co-resident workgroups otherwise run their phases in lockstep (all waiting on HBM, then all on the MFMA
+    // pipe, then all storing): de-phase them once at launch; the offset persists as slots are refilled.
+    const int d = (int)(((unsigned)blockIdx.x * 2654435761u) >> 30) * p.stagger;   // 0..3 x stagger
+    for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(8);
+  }
   IQ_STAMP(0);
   const int nk = p.K / BK2;
   issue(0);
@@ -355,13 +235,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
   }
   IQ_STAMP(2);
   IQ_STAMP(3);
-  gemm_epilogue<BN, EPI>(p, acc, m0, n0, lane, wave);
+  gemm_epilogue<4, BN / 32, EPI>(p, acc, m0 + (wave >> 1) * 64, n0 + (wave & 1) * (BN / 2), lane);
   IQ_STAMP(4);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   IQ_STAMP(5);
 }
 
 }  // namespace
+
+int iq_gemm_ws_try_launch(const GemmParams& p, int epi_mode, hipStream_t st);   // gemm_ws.hip
 
 #ifdef IQ_GEMM_STAMPS
 static unsigned long long* g_stamps = nullptr;
@@ -406,6 +288,12 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   int epi_mode = (p.residual ? EPI_RES : 0) | (p.gate ? EPI_GATE : 0) | ((p.pe || p.tok > 0) ? EPI_PE : 0);
   if ((epi_mode & EPI_PE) && (!p.pe || p.tok <= 0 || (epi_mode & (EPI_RES | EPI_GATE)))) return IQ_ERR_UNSUPPORTED;
   if (p.bias && ((uintptr_t)p.bias % 16)) return IQ_ERR_ARG;
+  static const int stagger = getenv("IQ_GEMM_STAGGER") ? atoi(getenv("IQ_GEMM_STAGGER")) : 2;   // measured best of {0,2,6}
+  p.stagger = stagger;
+  // The weight-stationary persistent kernel (gemm_ws.hip) is correct but measured 5-25 % SLOWER than the tiled
+  // kernels on the ViT-Tiny shapes (one 8-wave workgroup per CU serialises its own phases): opt-in only.
+  static const bool use_ws = getenv("IQ_GEMM_WS") != nullptr;
+  if (use_ws && !force_reg && iq_gemm_ws_try_launch(p, epi_mode, st) == IQ_OK) return iq_launch_status();
   const size_t lds_async = (size_t)3 * (BM + bn) * 32 * 2;     // ring of 3 stages
   const size_t lds_reg = (size_t)(BM + bn) * BK * 2;
 #define IQ_GEMM_LAUNCH(BN_, EPI_)                                                                  \
