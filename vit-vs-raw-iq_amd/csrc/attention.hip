@@ -266,82 +266,59 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const bf16* __res
   }
   __syncthreads();
 
-  // ---- phase A: wave owns 32 keys, sweeps queries; dV^T, dK^T in registers ---------------------
-  for (int kblk = wave; kblk < nblk; kblk += ATT_WAVES) {
-    bf16x8 kf[2][C::KS], vf[2][C::KS];
+  // ---- phase A: wave owns 16 keys, sweeps queries; dV^T, dK^T in registers ---------------------
+  // (16-key units keep the kernel at <= 128 VGPRs, so two 8-wave workgroups share a CU and one's staging /
+  //  dependency stalls overlap the other's MFMAs; 32-key units needed 195 VGPRs = one workgroup per CU.)
+  const int nunit = spad / 16;
+  for (int unit = wave; unit < nunit; unit += ATT_WAVES) {
+    bf16x8 kf[C::KS], vf[C::KS];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int s = 0; s < C::KS; ++s) {
+      kf[s] = row_frag_gmem<DH>(kb_, ldg, unit * 16 + c16, S, s, lane);
+      vf[s] = row_frag_gmem<DH>(vb_, ldg, unit * 16 + c16, S, s, lane);
+    }
+    f32x4 dv[C::DT], dk[C::DT];
 #pragma unroll
-      for (int s = 0; s < C::KS; ++s) {
-        kf[kt][s] = row_frag_gmem<DH>(kb_, ldg, kblk * 32 + kt * 16 + c16, S, s, lane);
-        vf[kt][s] = row_frag_gmem<DH>(vb_, ldg, kblk * 32 + kt * 16 + c16, S, s, lane);
-      }
-    f32x4 dv[C::DT][2], dk[C::DT][2];
-#pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt)
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) { dv[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int dt = 0; dt < C::DT; ++dt) { dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int key = unit * 16 + c16;
     for (int qblk = 0; qblk < nblk; ++qblk) {
-      f32x4 p[2][2], ds[2][2];   // [u][kt]
+      f32x4 p[2], ds[2];   // [u]
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        bf16x8 qa[C::KS], da[C::KS];
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < C::KS; ++s) {
-          qa[s] = row_frag_lds<DH>(I0, qblk * 32 + u * 16 + c16, s, lane);
-          da[s] = row_frag_lds<DH>(I1, qblk * 32 + u * 16 + c16, s, lane);
+          const bf16x8 qa = row_frag_lds<DH>(I0, qblk * 32 + u * 16 + c16, s, lane);
+          const bf16x8 da = row_frag_lds<DH>(I1, qblk * 32 + u * 16 + c16, s, lane);
+          sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[s], sa, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[s], dp, 0, 0, 0);
         }
-        float lq[4], dq_[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          lq[r] = lse_s[qblk * 32 + u * 16 + 4 * g + r];
-          dq_[r] = del_s[qblk * 32 + u * 16 + 4 * g + r];
-        }
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-          f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int s = 0; s < C::KS; ++s) {
-            sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[s], kf[kt][s], sa, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[s], vf[kt][s], dp, 0, 0, 0);
-          }
-          const int key = kblk * 32 + kt * 16 + c16;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int q = qblk * 32 + u * 16 + 4 * g + r;
-            float pv = exp2f(sa[r] * scale_log2 - lq[r]);
-            pv = (key < S && q < S) ? pv : 0.f;
-            p[u][kt][r] = pv;
-            ds[u][kt][r] = pv * (dp[r] - dq_[r]) * scale;
-          }
+          const int q = qblk * 32 + u * 16 + 4 * g + r;
+          float pv = exp2f(sa[r] * scale_log2 - lse_s[q]);
+          pv = (key < S && q < S) ? pv : 0.f;
+          p[u][r] = pv;
+          ds[u][r] = pv * (dp[r] - del_s[q]) * scale;
         }
       }
-      bf16x8 pB[2], dsB[2];
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) { pB[kt] = pack_b(p[0][kt], p[1][kt]); dsB[kt] = pack_b(ds[0][kt], ds[1][kt]); }
+      const bf16x8 pB = pack_b(p[0], p[1]), dsB = pack_b(ds[0], ds[1]);
 #pragma unroll
       for (int dt = 0; dt < C::DT; ++dt) {
         const bf16x8 doT = tr_frag(I1, C::LD, qblk * 32, dt * 16, lane);
         const bf16x8 qT = tr_frag(I0, C::LD, qblk * 32, dt * 16, lane);
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-          dv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doT, pB[kt], dv[dt][kt], 0, 0, 0);
-          dk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, dsB[kt], dk[dt][kt], 0, 0, 0);
-        }
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doT, pB, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, dsB, dk[dt], 0, 0, 0);
       }
     }
+    if (key < S) {
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      const int key = kblk * 32 + kt * 16 + c16;
-      if (key < S) {
+      for (int dt = 0; dt < C::DT; ++dt) {
+        bf16x4 wk, wv;
 #pragma unroll
-        for (int dt = 0; dt < C::DT; ++dt) {
-          bf16x4 wk, wv;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { wk[r] = (bf16)dk[dt][kt][r]; wv[r] = (bf16)dv[dt][kt][r]; }
-          *reinterpret_cast<bf16x4*>(dqb + (long)key * ldg + D + dt * 16 + 4 * g) = wk;
-          *reinterpret_cast<bf16x4*>(dqb + (long)key * ldg + 2 * D + dt * 16 + 4 * g) = wv;
-        }
+        for (int r = 0; r < 4; ++r) { wk[r] = (bf16)dk[dt][r]; wv[r] = (bf16)dv[dt][r]; }
+        *reinterpret_cast<bf16x4*>(dqb + (long)key * ldg + D + dt * 16 + 4 * g) = wk;
+        *reinterpret_cast<bf16x4*>(dqb + (long)key * ldg + 2 * D + dt * 16 + 4 * g) = wv;
       }
     }
   }

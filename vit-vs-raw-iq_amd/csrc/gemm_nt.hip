@@ -137,13 +137,13 @@ __device__ __forceinline__ int swz64(int row) { return (0x78 >> (((row >> 2) & 3
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 
-template <int BN, int EPI>
+template <int BMT, int BN, int EPI>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmParams p) {
   constexpr int BK2 = 32;
-  constexpr int WN = BN / 2, NT = WN / 16, MT = 4;
-  constexpr int STAGE_BYTES = (BM + BN) * BK2 * 2;     // 16 KiB | 12 KiB
+  constexpr int WN = BN / 2, NT = WN / 16, MT = BMT / 32;   // wave tile = BMT/2 rows x BN/2 cols
+  constexpr int STAGE_BYTES = (BMT + BN) * BK2 * 2;
   constexpr int NS = 3;
-  constexpr int A_LD = BM * BK2 * 2 / (4 * 1024);      // 1 KiB DMA pieces per wave per stage: A 2
+  constexpr int A_LD = BMT * BK2 * 2 / (4 * 1024);     // 1 KiB DMA pieces per wave per stage: A 2 | 1
   constexpr int B_LD = BN * BK2 * 2 / (4 * 1024);      //                                      B 2 | 1
   constexpr int PER_STAGE = A_LD + B_LD;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
   const int wm = wave >> 1, wn = wave & 1;
   const int ntiles = p.tiles_m * p.tiles_n;
   const int t = xcd_remap(blockIdx.x, ntiles);
-  const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
+  const int m0 = (t / p.tiles_n) * BMT, n0 = (t % p.tiles_n) * BN;
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
 #pragma unroll
     for (int i = 0; i < B_LD; ++i)
       __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(b_src[i] + ks * BK2),
-                                       (lds_void_t*)(st + BM * BK2 * 2 + (wave * B_LD + i) * 1024), 16, 0, 0);
+                                       (lds_void_t*)(st + BMT * BK2 * 2 + (wave * B_LD + i) * 1024), 16, 0, 0);
   };
 
 #ifdef IQ_GEMM_STAMPS
@@ -204,7 +204,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
   if (nk > 1) issue(1);
   for (int ks = 0; ks < nk; ++ks) {
     if (ks + 1 < nk) {
-      if (PER_STAGE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (PER_STAGE == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if (PER_STAGE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -214,12 +215,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
     if (ks == 0) IQ_STAMP(1);
     if (ks + 2 < nk) issue(ks + 2);    // refills the slot stage ks-1 just vacated
     const bf16* As = reinterpret_cast<const bf16*>(smem + (ks % NS) * STAGE_BYTES);
-    const bf16* Bs = As + BM * BK2;
+    const bf16* Bs = As + BMT * BK2;
     bf16x8 af[MT], bfr[NT];
     const int ch = lane >> 4;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int row = wm * 64 + i * 16 + (lane & 15);
+      const int row = wm * (BMT / 2) + i * 16 + (lane & 15);
       af[i] = *reinterpret_cast<const bf16x8*>(As + row * BK2 + (ch ^ swz64(row)) * 8);
     }
 #pragma unroll
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
   }
   IQ_STAMP(2);
   IQ_STAMP(3);
-  gemm_epilogue<4, BN / 32, EPI>(p, acc, m0 + (wave >> 1) * 64, n0 + (wave & 1) * (BN / 2), lane);
+  gemm_epilogue<MT, NT, EPI>(p, acc, m0 + (wave >> 1) * (BMT / 2), n0 + (wave & 1) * (BN / 2), lane);
   IQ_STAMP(4);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   IQ_STAMP(5);
@@ -278,13 +279,20 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   }
   hipStream_t st = (hipStream_t)stream;
   IQ_PROF(IQ_FAM_GEMM_NT, st);
-  p.tiles_m = (M + BM - 1) / BM;
-  const bool wide = (N % 128 == 0 || N > 512);
-  const int bn = wide ? 128 : 64;
-  p.tiles_n = (N + bn - 1) / bn;
-  const int grid = p.tiles_m * p.tiles_n;
+  static const int bm_env = getenv("IQ_GEMM_BM") ? atoi(getenv("IQ_GEMM_BM")) : 0;
   static const bool force_reg = getenv("IQ_GEMM_FORCE_REG") != nullptr;   // diagnostics: register-staged path
   const bool async_ok = !force_reg && (K % 32 == 0) && (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
+  // Column tile: 192 when it divides N (ViT-Tiny: 192, 576, 768 -- fewer re-reads of the A rows and of the
+  // weight tile per output byte), else 128 for wide N, else 64.  IQ_GEMM_BN=64|128 overrides (diagnostics).
+  static const int bn_env = getenv("IQ_GEMM_BN") ? atoi(getenv("IQ_GEMM_BN")) : 0;
+  const bool wide = (N % 128 == 0 || N > 512);
+  int bn = wide ? 128 : 64;
+  if (bn_env == 192 && N % 192 == 0 && async_ok) bn = 192;
+  if (bn_env == 64 || bn_env == 128) bn = (bn_env == 128 && !wide) ? 64 : bn_env;
+  const int bm = (async_ok && bm_env == 64) ? 64 : BM;
+  p.tiles_m = (M + bm - 1) / bm;
+  p.tiles_n = (N + bn - 1) / bn;
+  const int grid = p.tiles_m * p.tiles_n;
   int epi_mode = (p.residual ? EPI_RES : 0) | (p.gate ? EPI_GATE : 0) | ((p.pe || p.tok > 0) ? EPI_PE : 0);
   if ((epi_mode & EPI_PE) && (!p.pe || p.tok <= 0 || (epi_mode & (EPI_RES | EPI_GATE)))) return IQ_ERR_UNSUPPORTED;
   if (p.bias && ((uintptr_t)p.bias % 16)) return IQ_ERR_ARG;
@@ -294,12 +302,13 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   // kernels on the ViT-Tiny shapes (one 8-wave workgroup per CU serialises its own phases): opt-in only.
   static const bool use_ws = getenv("IQ_GEMM_WS") != nullptr;
   if (use_ws && !force_reg && iq_gemm_ws_try_launch(p, epi_mode, st) == IQ_OK) return iq_launch_status();
-  const size_t lds_async = (size_t)3 * (BM + bn) * 32 * 2;     // ring of 3 stages
+  const size_t lds_async = (size_t)3 * (bm + bn) * 32 * 2;     // ring of 3 stages
   const size_t lds_reg = (size_t)(BM + bn) * BK * 2;
 #define IQ_GEMM_LAUNCH(BN_, EPI_)                                                                  \
   do {                                                                                             \
-    if (async_ok) gemm_nt_async_kernel<BN_, EPI_><<<grid, GEMM_THREADS, lds_async, st>>>(p);       \
-    else gemm_nt_kernel<BN_, EPI_><<<grid, GEMM_THREADS, lds_reg, st>>>(p);                        \
+    if (async_ok && bm == 64) gemm_nt_async_kernel<64, BN_, EPI_><<<grid, GEMM_THREADS, lds_async, st>>>(p);   \
+    else if (async_ok) gemm_nt_async_kernel<128, BN_, EPI_><<<grid, GEMM_THREADS, lds_async, st>>>(p);       \
+    else gemm_nt_kernel<(BN_ == 192 ? 128 : BN_), EPI_><<<grid, GEMM_THREADS, lds_reg, st>>>(p);   \
   } while (0)
 #define IQ_GEMM_EPI(BN_)                                                       \
   switch (epi_mode) {                                                          \
@@ -310,7 +319,7 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
     case EPI_PE: IQ_GEMM_LAUNCH(BN_, EPI_PE); break;                           \
     default: return IQ_ERR_UNSUPPORTED;                                        \
   }
-  if (wide) { IQ_GEMM_EPI(128) } else { IQ_GEMM_EPI(64) }
+  if (bn == 192) { IQ_GEMM_EPI(192) } else if (bn == 128) { IQ_GEMM_EPI(128) } else { IQ_GEMM_EPI(64) }
 #undef IQ_GEMM_EPI
 #undef IQ_GEMM_LAUNCH
   return iq_launch_status();
