@@ -163,24 +163,24 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16* __restri
   }
 }
 
-// column sums of the per-block partials: 32 columns x 8 row-slices per block, coalesced 128 B rows
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int D,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int accumulate) {
-  __shared__ float sm[8][33];
+// column sums of the per-block partials: 32 columns x 32 row-slices per block (1024 threads), coalesced 128 B rows
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int D,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             int accumulate) {
+  __shared__ float sm[32][33];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
   if (c < 2 * D) {
 #pragma unroll 4
-    for (int b = sl; b < nblk; b += 8) s += partial[(long)b * 2 * D + c];
+    for (int b = sl; b < nblk; b += 32) s += partial[(long)b * 2 * D + c];
   }
   sm[sl][cl] = s;
   __syncthreads();
   if (sl == 0 && c < 2 * D) {
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t += sm[i][cl];
+    for (int i = 0; i < 32; ++i) t += sm[i][cl];
     float* dst = c < D ? dgamma + c : dbeta + (c - D);
     *dst = accumulate ? *dst + t : t;
   }
@@ -283,7 +283,7 @@ extern "C" int iq_ln_bwd(const void* dx, const void* z, const float* mean, const
       k<<<nblk, LN_THREADS, lds, st>>>((const bf16*)dx, (const bf16*)z, mean, rstd, gamma, (bf16*)dz, (bf16*)dy, rng,
                                        thresh, dscale, ws, M, D);
     }
-    ln_bwd_reduce_kernel<<<(2 * D + 31) / 32, 256, 0, st>>>(ws, nblk, D, dgamma, dbeta, accumulate);
+    ln_bwd_reduce_kernel<<<(2 * D + 31) / 32, 1024, 0, st>>>(ws, nblk, D, dgamma, dbeta, accumulate);
   });
   if (!ok) return IQ_ERR_UNSUPPORTED;
   return rc != IQ_OK ? rc : iq_launch_status();

@@ -26,6 +26,17 @@ __global__ void patchify_kernel(const float* __restrict__ src, bf16* __restrict_
     const long row = id / (Kpad / 8);
     const int b = (int)(row / tok), t = (int)(row % tok);
     float v[8];
+    if (kind == 0 && (p & 7) == 0 && (W & 3) == 0 && ch * 8 < P) {
+      // 8 consecutive px of one (c, py): 32 contiguous, 16 B-aligned source bytes
+      const int k = ch * 8, gw = W / p;
+      const int c = k / (p * p), rem = k % (p * p), py = rem / p, px = rem % p;
+      const int gy = t / gw, gx = t % gw;
+      const float* sp = src + (((long)b * C + c) * H + gy * p + py) * W + gx * p + px;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(sp), bq = *reinterpret_cast<const f32x4*>(sp + 4);
+      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = bq[0]; v[5] = bq[1]; v[6] = bq[2]; v[7] = bq[3];
+      *reinterpret_cast<bf16x8*>(dst + row * Kpad + ch * 8) = pack8(v);
+      continue;
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int k = ch * 8 + e;
@@ -243,35 +254,51 @@ __global__ __launch_bounds__(64) void head_bwd_dx_kernel(const float* __restrict
   }
 }
 
-// dW[k,d], db[k], dln_g[d], dln_b[d]: thread per (k,d) (+ one extra "row" k==K for the LN grads)
-__global__ void head_bwd_w_kernel(const float* __restrict__ dlogits, const float* __restrict__ feat_hat,
-                                  const float* __restrict__ ln_g, const float* __restrict__ ln_b,
-                                  const float* __restrict__ W, float* __restrict__ dW, float* __restrict__ db,
-                                  float* __restrict__ dln_g, float* __restrict__ dln_b, int B, int D, int K,
-                                  int accumulate) {
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+// dW[k,d], db[k], dln_g[d], dln_b[d]: block = 32 (k,d) outputs x 8 frame slices (+ one extra "row" k==K for
+// the LN grads); the slices are combined through LDS in fixed order.
+__global__ __launch_bounds__(256) void head_bwd_w_kernel(const float* __restrict__ dlogits, const float* __restrict__ feat_hat,
+                                                         const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                         const float* __restrict__ W, float* __restrict__ dW, float* __restrict__ db,
+                                                         float* __restrict__ dln_g, float* __restrict__ dln_b, int B, int D, int K,
+                                                         int accumulate) {
+  __shared__ float sa[8][33], sb[8][33];
+  const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int id = blockIdx.x * 32 + ol;
   const int k = id / D, d = id % D;
-  if (k > K || (k == K && !ln_g)) return;
-  if (k < K) {
-    float a = 0.f, sb = 0.f;
-    const float g = ln_g ? ln_g[d] : 1.f, be = ln_g ? ln_b[d] : 0.f;
-    for (int b = 0; b < B; ++b) {
-      const float dl = dlogits[(long)b * K + k];
-      a += dl * (g * feat_hat[(long)b * D + d] + be);
-      sb += dl;
+  const bool live = k < K || (k == K && ln_g);
+  float a = 0.f, b2 = 0.f;
+  if (live) {
+    if (k < K) {
+      const float g = ln_g ? ln_g[d] : 1.f, be = ln_g ? ln_b[d] : 0.f;
+#pragma unroll 4
+      for (int b = sl; b < B; b += 8) {
+        const float dl = dlogits[(long)b * K + k];
+        a += dl * (g * feat_hat[(long)b * D + d] + be);
+        b2 += dl;
+      }
+    } else {
+      for (int b = sl; b < B; b += 8) {
+        float dfn = 0.f;
+        for (int kk = 0; kk < K; ++kk) dfn += dlogits[(long)b * K + kk] * W[(long)kk * D + d];
+        a += dfn * feat_hat[(long)b * D + d];
+        b2 += dfn;
+      }
     }
-    dW[(long)k * D + d] = accumulate ? dW[(long)k * D + d] + a : a;
-    if (d == 0) db[k] = accumulate ? db[k] + sb : sb;
-  } else {
-    float ag = 0.f, ab = 0.f;
-    for (int b = 0; b < B; ++b) {
-      float dfn = 0.f;
-      for (int kk = 0; kk < K; ++kk) dfn += dlogits[(long)b * K + kk] * W[(long)kk * D + d];
-      ag += dfn * feat_hat[(long)b * D + d];
-      ab += dfn;
+  }
+  sa[sl][ol] = a;
+  sb[sl][ol] = b2;
+  __syncthreads();
+  if (sl == 0 && live) {
+    float ta = 0.f, tb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ta += sa[i][ol]; tb += sb[i][ol]; }
+    if (k < K) {
+      dW[(long)k * D + d] = accumulate ? dW[(long)k * D + d] + ta : ta;
+      if (d == 0) db[k] = accumulate ? db[k] + tb : tb;
+    } else {
+      dln_g[d] = accumulate ? dln_g[d] + ta : ta;
+      dln_b[d] = accumulate ? dln_b[d] + tb : tb;
     }
-    dln_g[d] = accumulate ? dln_g[d] + ag : ag;
-    dln_b[d] = accumulate ? dln_b[d] + ab : ab;
   }
 }
 
@@ -481,7 +508,7 @@ extern "C" int iq_head_bwd(const float* dlogits, const float* featn, const float
   hipStream_t st = (hipStream_t)stream;
   head_bwd_dx_kernel<<<B, 64, D * sizeof(float), st>>>(dlogits, featn, hstat, ln_g, W, (bf16*)dx, S, D, K, pool);
   const int n = (K + 1) * D;
-  head_bwd_w_kernel<<<(n + 255) / 256, 256, 0, st>>>(dlogits, featn, ln_g, ln_b, W, dW, db, dln_g, dln_b, B, D, K, accumulate);
+  head_bwd_w_kernel<<<(n + 31) / 32, 256, 0, st>>>(dlogits, featn, ln_g, ln_b, W, dW, db, dln_g, dln_b, B, D, K, accumulate);
   return iq_launch_status();
 }
 
