@@ -59,7 +59,7 @@ def stream():
 # ------------------------------------------------------------------------------------------------
 # LayerNorm
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("D", [64, 128, 192, 256, 768, 32, 96])
+@pytest.mark.parametrize("D", [64, 128, 192, 256, 768, 32, 96, 136, 176, 1048])
 @pytest.mark.parametrize("M", [1, 37, 4100])
 def test_ln_fwd_bwd(L, D, M):
     N = _N()
@@ -107,8 +107,9 @@ def test_ln_fwd_bwd(L, D, M):
 
 
 def test_ln_unsupported_width_is_refused(L):
-    assert L.iq_ln_supported(20) == 0
-    assert L.iq_ln_supported(136) == 0      # 17 vectors per row: not instantiated
+    assert L.iq_ln_supported(20) == 0       # rows must be whole 16-byte vectors
+    assert L.iq_ln_supported(136) == 1      # 17 vectors per row: masked one-wave-per-row fallback
+    assert L.iq_ln_supported(4096) == 0
 
 
 # ------------------------------------------------------------------------------------------------

@@ -22,7 +22,7 @@ __device__ __forceinline__ float group_sum(float v) {
 
 constexpr int LN_THREADS = 256;
 
-template <int LPR, int NV>
+template <int LPR, int NV, bool MASK = false>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const bf16* __restrict__ Z, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16* __restrict__ X,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -35,8 +35,9 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const bf16* __restri
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const int c = (v * LPR + j) * 8;
+    const bool cv = !MASK || c < D;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { g[v][e] = gamma[c + e]; b[v][e] = beta[c + e]; }
+    for (int e = 0; e < 8; ++e) { g[v][e] = cv ? gamma[c + e] : 0.f; b[v][e] = cv ? beta[c + e] : 0.f; }
   }
   const float invD = 1.0f / (float)D;
   for (long row0 = (long)blockIdx.x * RPB; row0 < M; row0 += (long)gridDim.x * RPB) {
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const bf16* __restri
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       bf16x8 t = {};
-      if (ok) t = *reinterpret_cast<const bf16x8*>(Z + row * D + (v * LPR + j) * 8);
+      if (ok && (!MASK || (v * LPR + j) * 8 < D)) t = *reinterpret_cast<const bf16x8*>(Z + row * D + (v * LPR + j) * 8);
       unpack8(t, x[v]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += x[v][e];
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const bf16* __restri
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { float d = x[v][e] - mean; q += d * d; }
+      for (int e = 0; e < 8; ++e) { float d = x[v][e] - mean; q += (!MASK || (v * LPR + j) * 8 < D) ? d * d : 0.f; }
     const float var = group_sum<LPR>(q) * invD;
     const float rstd = 1.0f / sqrtf(var + eps);
     if (ok) {
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const bf16* __restri
         float y[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) y[e] = g[v][e] * ((x[v][e] - mean) * rstd) + b[v][e];
-        *reinterpret_cast<bf16x8*>(X + row * D + (v * LPR + j) * 8) = pack8(y);
+        if (!MASK || (v * LPR + j) * 8 < D) *reinterpret_cast<bf16x8*>(X + row * D + (v * LPR + j) * 8) = pack8(y);
       }
       if (j == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
     }
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const bf16* __restri
 // regenerated from the Philox counter, never stored.
 // dgamma/dbeta: per-lane register accumulation over the block's rows -> LDS -> one partial row
 // per block; ln_bwd_reduce_kernel sums the partials (deterministic, no atomics).
-template <int LPR, int NV, bool DROP>
+template <int LPR, int NV, bool DROP, bool MASK = false>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16* __restrict__ dX, const bf16* __restrict__ Z,
                                                             const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                             const float* __restrict__ gamma, bf16* __restrict__ dZ,
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16* __restri
   for (int v = 0; v < NV; ++v) {
     const int c = (v * LPR + j) * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { g[v][e] = gamma[c + e]; ag[v][e] = 0.f; ab[v][e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { g[v][e] = (!MASK || c < D) ? gamma[c + e] : 0.f; ag[v][e] = 0.f; ab[v][e] = 0.f; }
   }
   const float invD = 1.0f / (float)D;
   if (DROP) rng = rng_resolve(rng);
@@ -109,7 +110,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16* __restri
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       bf16x8 tz = {}, td = {};
-      if (ok) {
+      const bool cv = !MASK || (v * LPR + j) * 8 < D;
+      if (ok && cv) {
         tz = *reinterpret_cast<const bf16x8*>(Z + row * D + (v * LPR + j) * 8);
         td = *reinterpret_cast<const bf16x8*>(dX + row * D + (v * LPR + j) * 8);
       }
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16* __restri
       unpack8(td, dy[v]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        xh[v][e] = (xh[v][e] - mean) * rstd;
+        xh[v][e] = cv ? (xh[v][e] - mean) * rstd : 0.f;
         ag[v][e] += dy[v][e] * xh[v][e];
         ab[v][e] += dy[v][e];
         dy[v][e] *= g[v][e];
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16* __restri
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = rstd * (dy[v][e] - c1 - xh[v][e] * c2);
         const long off = row * D + (v * LPR + j) * 8;
+        if (MASK && (v * LPR + j) * 8 >= D) continue;
         *reinterpret_cast<bf16x8*>(dZ + off) = pack8(o);
         if (DROP) {
           const uint32_t keep = dropout_keep8(rng, (uint64_t)off >> 3, thresh);
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16* __restri
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const int c = (v * LPR + j) * 8;
+    if (MASK && c >= D) continue;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       red[rslot * 2 * D + c + e] = ag[v][e];
@@ -209,6 +213,18 @@ inline bool ln_dispatch(const LnShape& s, F&& f) {
 #undef IQ_LN_CASE
   return false;
 }
+// any other D % 8 == 0 up to 2048: one wave per row, lanes past D/8 vectors masked off (slower, always correct)
+inline int ln_masked_nv(int D) { return (D % 8 == 0 && D > 0 && D <= 2048) ? (D / 8 + 63) / 64 : 0; }
+template <typename F>
+inline bool ln_dispatch_masked(int D, F&& f) {
+  switch (ln_masked_nv(D)) {
+    case 1: f(std::integral_constant<int, 1>{}); return true;
+    case 2: f(std::integral_constant<int, 2>{}); return true;
+    case 3: f(std::integral_constant<int, 3>{}); return true;
+    case 4: f(std::integral_constant<int, 4>{}); return true;
+    default: return false;
+  }
+}
 
 constexpr int LN_MAX_BLOCKS = 512;      // backward: one partial row per block
 constexpr int LN_FWD_MAX_BLOCKS = 4096;
@@ -225,7 +241,7 @@ inline int ln_grid(int M, int rpb, int cap = LN_MAX_BLOCKS) {
 extern "C" int iq_ln_supported(int D) {
   LnShape s;
   if (!ln_shape(D, &s)) return 0;
-  return ln_dispatch(s, [](auto, auto) {}) ? 1 : 0;
+  return (ln_dispatch(s, [](auto, auto) {}) || ln_masked_nv(D) > 0) ? 1 : 0;
 }
 
 extern "C" int iq_ln_fwd(const void* z, const float* gamma, const float* beta, void* x, float* mean, float* rstd,
@@ -240,6 +256,11 @@ extern "C" int iq_ln_fwd(const void* z, const float* gamma, const float* beta, v
     constexpr int LPR = decltype(lpr)::value, NV = decltype(nv)::value;
     ln_fwd_kernel<LPR, NV><<<ln_grid(M, (64 / LPR) * 4, LN_FWD_MAX_BLOCKS), LN_THREADS, 0, st>>>((const bf16*)z, gamma, beta, (bf16*)x, mean,
                                                                              rstd, M, D, eps);
+  });
+  if (!ok) ok = ln_dispatch_masked(D, [&](auto nv) {
+    constexpr int NV = decltype(nv)::value;
+    ln_fwd_kernel<64, NV, true><<<ln_grid(M, 4, LN_FWD_MAX_BLOCKS), LN_THREADS, 0, st>>>((const bf16*)z, gamma, beta, (bf16*)x,
+                                                                                         mean, rstd, M, D, eps);
   });
   return ok ? iq_launch_status() : IQ_ERR_UNSUPPORTED;
 }
@@ -283,6 +304,19 @@ extern "C" int iq_ln_bwd(const void* dx, const void* z, const float* mean, const
       k<<<nblk, LN_THREADS, lds, st>>>((const bf16*)dx, (const bf16*)z, mean, rstd, gamma, (bf16*)dz, (bf16*)dy, rng,
                                        thresh, dscale, ws, M, D);
     }
+    ln_bwd_reduce_kernel<<<(2 * D + 31) / 32, 1024, 0, st>>>(ws, nblk, D, dgamma, dbeta, accumulate);
+  });
+  if (!ok) ok = ln_dispatch_masked(D, [&](auto nv) {
+    constexpr int NV = decltype(nv)::value;
+    constexpr int RPB = 4;
+    const int nblk = ln_grid(M, RPB);
+    const size_t lds = (size_t)RPB * 2 * D * sizeof(float);
+    if (dropping)
+      ln_bwd_kernel<64, NV, true, true><<<nblk, LN_THREADS, lds, st>>>((const bf16*)dx, (const bf16*)z, mean, rstd, gamma,
+                                                                      (bf16*)dz, (bf16*)dy, rng, thresh, dscale, ws, M, D);
+    else
+      ln_bwd_kernel<64, NV, false, true><<<nblk, LN_THREADS, lds, st>>>((const bf16*)dx, (const bf16*)z, mean, rstd, gamma,
+                                                                       (bf16*)dz, (bf16*)dy, rng, thresh, dscale, ws, M, D);
     ln_bwd_reduce_kernel<<<(2 * D + 31) / 32, 1024, 0, st>>>(ws, nblk, D, dgamma, dbeta, accumulate);
   });
   if (!ok) return IQ_ERR_UNSUPPORTED;
