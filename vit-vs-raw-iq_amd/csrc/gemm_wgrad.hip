@@ -157,10 +157,15 @@ __global__ __launch_bounds__(WG_THREADS, 4) void wgrad_kernel(const WgradParams 
 // out[i] (+)= sum_s slab[s][i].  Block = 64 float4 columns x 4 split slices (coalesced 1 KiB rows, 4x the
 // loads in flight of a one-thread-per-column loop), slices combined through LDS in fixed order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, long n, int splits,
-                                                           float* __restrict__ out, int accumulate) {
+                                                           float* __restrict__ out, const float* __restrict__ bslab,
+                                                           long nb, float* __restrict__ bout, int accumulate) {
+  // blocks [0, nblk_w) reduce the weight slabs, the remaining ones the bias slabs (one launch for both)
   __shared__ f32x4 part[4][64];
+  const long nblk_w = (n + 255) / 256;
+  if ((long)blockIdx.x >= nblk_w) { slab = bslab; n = nb; out = bout; }
+  const long blk = (long)blockIdx.x >= nblk_w ? (long)blockIdx.x - nblk_w : (long)blockIdx.x;
   const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const long i = ((long)blockIdx.x * 64 + col) * 4;
+  const long i = (blk * 64 + col) * 4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (i + 4 <= n) {
 #pragma unroll 4
@@ -238,7 +243,7 @@ extern "C" int iq_gemm_bf16_wgrad(const void* dY, int ldy, const void* X, int ld
     wgrad_kernel<64><<<grid, WG_THREADS, lds, st>>>(q);
   }
   const long n = (long)N * K;
-  wgrad_reduce_kernel<<<(int)((n + 255) / 256), 256, 0, st>>>(p.slab, n, w.splits, dW, accumulate);
-  if (dbias) wgrad_reduce_kernel<<<(N + 255) / 256, 256, 0, st>>>(p.bslab, N, w.splits, dbias, accumulate);
+  const int nblk_w = (int)((n + 255) / 256), nblk_b = dbias ? (N + 255) / 256 : 0;
+  wgrad_reduce_kernel<<<nblk_w + nblk_b, 256, 0, st>>>(p.slab, n, w.splits, dW, p.bslab, (long)N, dbias, accumulate);
   return iq_launch_status();
 }
