@@ -82,6 +82,22 @@ size_t iq_wgrad_ws_bytes(int M, int N, int K);
 int iq_gemm_bf16_wgrad(const void* dY, int ldy, const void* X, int ldx, float* dW, float* dbias, int M, int N, int K,
                        float* ws, size_t ws_bytes, int accumulate, iq_stream_t stream);
 
+/* Several weight gradients that share M (the four Linear layers of one encoder layer: what torch.autograd runs as
+ * separate addmm nodes behind V/models/blocks/encoder_layer.py:16-36) in ONE launch + ONE slab reduce.  At most 4
+ * problems are fused; larger groups / large N*K run one at a time through the same workspace. */
+typedef struct iq_wgrad_problem {
+  const void* dY; /* bf16 [M, ldy] */
+  int ldy;
+  const void* X;  /* bf16 [M, ldx] */
+  int ldx;
+  float* dW;      /* fp32 [N, K], 16-byte aligned */
+  float* dbias;   /* fp32 [N] or NULL */
+  int N, K;
+} iq_wgrad_problem_t;
+size_t iq_wgrad_grouped_ws_bytes(const iq_wgrad_problem_t* probs, int nprob, int M);
+int iq_gemm_bf16_wgrad_grouped(const iq_wgrad_problem_t* probs, int nprob, int M, float* ws, size_t ws_bytes,
+                               int accumulate, iq_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Scaled-dot-product attention core, softmax(Q K^T / sqrt(dh)) V per (frame, head), no mask,
  * no dropout.  Replaces ScaleDotProductAttention.forward

@@ -238,7 +238,8 @@ def test_dropout_statistics_and_regeneration(L):
 # weight gradient
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N_,K", [(64, 128, 128), (1000, 192, 192), (5000, 768, 192), (3333, 192, 768),
-                                    (777, 576, 192), (130, 40, 72), (4096, 128, 32), (20000, 128, 1024)])
+                                    (777, 576, 192), (130, 40, 72), (4096, 128, 32), (20000, 128, 1024),
+                                    (31, 64, 64), (700, 1024, 768)])   # last: N*K > 512 Ki -> shared-tile kernel
 def test_wgrad(L, M, N_, K):
     N = _N()
     g = torch.Generator(device="cuda").manual_seed(M + 3 * N_ + K)
@@ -256,6 +257,40 @@ def test_wgrad(L, M, N_, K):
     N.check(L.iq_gemm_bf16_wgrad(dY.data_ptr(), N_, X.data_ptr(), K, dW.data_ptr(), db.data_ptr(), M, N_, K,
                                  ws.data_ptr(), nbytes, 1, stream()), "wgrad acc")
     close_f32(dW, 2 * ref, "dW acc")
+
+
+@pytest.mark.parametrize("M,shapes", [
+    (3940, [(192, 768), (768, 192), (192, 192), (576, 192)]),     # one ViT-Tiny encoder layer
+    (1000, [(128, 256), (40, 72)]),                               # partial tiles, two problems
+    (515, [(64, 64), (1024, 768), (72, 64)]),                     # a large member: falls back to one launch per problem
+])
+def test_wgrad_grouped(L, M, shapes):
+    """Several weight gradients sharing M in one launch == each one alone (fp64 reference), with and without accumulate."""
+    N = _N()
+    g = torch.Generator(device="cuda").manual_seed(M)
+    probs = (N.WgradProblem * len(shapes))()
+    keep, refs = [], []
+    for i, (n, k) in enumerate(shapes):
+        dY = bf(torch.randn(M, n + 8, device=dev(), generator=g))[:, :n]      # ld > N: strided operand
+        X = bf(torch.randn(M, k, device=dev(), generator=g))
+        dW = torch.full((n, k), 3.0, device=dev())
+        db = torch.full((n,), 3.0, device=dev()) if i != 1 else None          # one problem without bias
+        keep.append((dY, X, dW, db))
+        probs[i].dY = dY.data_ptr(); probs[i].ldy = n + 8; probs[i].X = X.data_ptr(); probs[i].ldx = k
+        probs[i].dW = dW.data_ptr(); probs[i].dbias = db.data_ptr() if db is not None else None
+        probs[i].N = n; probs[i].K = k
+        refs.append((dY.double().t() @ X.double(), dY.double().sum(0)))
+    nbytes = L.iq_wgrad_grouped_ws_bytes(probs, len(shapes), M)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
+    N.check(L.iq_gemm_bf16_wgrad_grouped(probs, len(shapes), M, ws.data_ptr(), nbytes, 0, stream()), "grouped")
+    for (dY, X, dW, db), (rw, rb) in zip(keep, refs):
+        close_f32(dW, rw, "dW")
+        if db is not None:
+            close_f32(db, rb, "db")
+    N.check(L.iq_gemm_bf16_wgrad_grouped(probs, len(shapes), M, ws.data_ptr(), nbytes, 1, stream()), "grouped acc")
+    for (dY, X, dW, db), (rw, rb) in zip(keep, refs):
+        close_f32(dW, 2 * rw, "dW acc")
+    assert L.iq_gemm_bf16_wgrad_grouped(probs, len(shapes), M, ws.data_ptr(), nbytes - 1, 0, stream()) != 0   # ws too small
 
 
 def test_wgrad_exact_integers(L):

@@ -29,6 +29,11 @@ class Epilogue(C.Structure):
                 ("gate_scale", C.c_float), ("residual", C.c_void_p), ("ldr", C.c_int)]
 
 
+class WgradProblem(C.Structure):
+    _fields_ = [("dY", C.c_void_p), ("ldy", C.c_int), ("X", C.c_void_p), ("ldx", C.c_int), ("dW", C.c_void_p),
+                ("dbias", C.c_void_p), ("N", C.c_int), ("K", C.c_int)]
+
+
 class ModelCfg(C.Structure):
     _fields_ = [("kind", C.c_int), ("in_channels", C.c_int), ("img_h", C.c_int), ("img_w", C.c_int),
                 ("patch", C.c_int), ("seq_length", C.c_int), ("conv_k", C.c_int), ("use_cls", C.c_int),
@@ -48,6 +53,8 @@ SIGNATURES = {
     "iq_gemm_bf16_nt": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, C.POINTER(Epilogue), _P]),
     "iq_wgrad_ws_bytes": (_Z, [_I, _I, _I]),
     "iq_gemm_bf16_wgrad": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _Z, _I, _P]),
+    "iq_wgrad_grouped_ws_bytes": (_Z, [_P, _I, _I]),
+    "iq_gemm_bf16_wgrad_grouped": (_I, [_P, _I, _I, _P, _Z, _I, _P]),
     "iq_attn_supported": (_I, [_I, _I]),
     "iq_attn_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "iq_attn_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -14,6 +14,8 @@
 // partial tile to a slab and wgrad_reduce_kernel sums the slabs in fixed order (bitwise
 // reproducible; float atomics would be both slower at this byte rate and order dependent).
 #include "common.h"
+#include <stdlib.h>
+#include <string.h>
 #include "iqvit.h"
 #include "prof.h"
 
@@ -21,7 +23,6 @@ namespace {
 
 constexpr int WG_THREADS = 512;   // 8 waves: 2 (n) x 4 (k); two workgroups per CU hide the HBM latency of the single-stage loop
 constexpr int TN = 128;     // output rows (n) per tile
-constexpr int MC = 64;      // contraction rows per LDS stage
 constexpr int YLD = TN + 16;  // padded LDS row (elements): 288 B rows -> conflict-free tr reads
 
 struct WgradParams {
@@ -30,7 +31,16 @@ struct WgradParams {
   float* slab;       // [splits][N*K]
   float* bslab;      // [splits][N] or null
   int tiles_n, tiles_k, splits, rows_per_split;
+#ifdef IQ_WGRAD_STAMPS
+  unsigned long long* stamps;   // diagnostic build only (scripts/wgrad_stamps.py): per-workgroup phase ticks
+#endif
 };
+
+#ifdef IQ_WGRAD_STAMPS
+#define IQ_WTICK(i) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn_) :: "memory"); tk_[i] += tn_ - tl_; tl_ = tn_; } while (0)
+#else
+#define IQ_WTICK(i) do {} while (0)
+#endif
 
 __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int ld, int r0, int c0, int lane) {
   // lane group g = lane>>4 takes k-slots {r0+4g+q} U {r0+16+4g+q}, q=0..3; column c0 + (lane&15)
@@ -43,7 +53,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int ld, int r0, int 
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int TK>
+// MC = contraction rows per LDS stage.  One stage is in flight per workgroup while the previous one is multiplied, so
+// the bytes in flight per CU (2 workgroups x MC x (TN+TK) x 2 B) against the ~2 us loaded memory latency set the
+// ingest rate: MC = 64 measured 7.7 TB/s at the L2 (Little's law limit), MC = 128 doubles the bytes in flight.
+template <int TK, int MC>
 __global__ __launch_bounds__(WG_THREADS, 4) void wgrad_kernel(const WgradParams p) {
   constexpr int XLD = TK + 16;
   constexpr int KT = TK / 64;       // 16-col k tiles per wave (wave tile = 64 n x TK/4 k)
@@ -106,14 +119,20 @@ __global__ __launch_bounds__(WG_THREADS, 4) void wgrad_kernel(const WgradParams 
     }
   };
 
+#ifdef IQ_WGRAD_STAMPS
+  unsigned long long tk_[6] = {0, 0, 0, 0, 0, 0}, tl_, tn_;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_) :: "memory");
+#endif
   if (mbeg < mend) {
     gload(mbeg);
     lstore();
   }
   __syncthreads();
+  IQ_WTICK(0);
   for (int mb = mbeg; mb < mend; mb += MC) {
     const bool more = mb + MC < mend;
     if (more) gload(mb + MC);
+    IQ_WTICK(1);
 #pragma unroll
     for (int s = 0; s < MC / 32; ++s) {
       bf16x8 af[4], bfr[KT];
@@ -129,12 +148,23 @@ __global__ __launch_bounds__(WG_THREADS, 4) void wgrad_kernel(const WgradParams 
         if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
       }
     }
+    IQ_WTICK(2);
     __syncthreads();
+    IQ_WTICK(3);
     if (more) {
+#ifdef IQ_WGRAD_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      IQ_WTICK(4);
+#endif
       lstore();
       __syncthreads();
+      IQ_WTICK(5);
     }
   }
+#ifdef IQ_WGRAD_STAMPS
+  if (tid == 0 && p.stamps)
+    for (int i = 0; i < 6; ++i) p.stamps[(long)blockIdx.x * 6 + i] = tk_[i];
+#endif
 
   float* out = p.slab + (long)split * p.N * p.K;
 #pragma unroll
@@ -154,16 +184,215 @@ __global__ __launch_bounds__(WG_THREADS, 4) void wgrad_kernel(const WgradParams 
   }
 }
 
-// out[i] (+)= sum_s slab[s][i].  Block = 64 float4 columns x 4 split slices (coalesced 1 KiB rows, 4x the
-// loads in flight of a one-thread-per-column loop), slices combined through LDS in fixed order.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, long n, int splits,
-                                                           float* __restrict__ out, const float* __restrict__ bslab,
-                                                           long nb, float* __restrict__ bout, int accumulate) {
-  // blocks [0, nblk_w) reduce the weight slabs, the remaining ones the bias slabs (one launch for both)
+// ---- wave-private variant (small N x K, the ViT-Tiny / raw-IQ shapes) ------------------------------------------------
+// Phase stamps of the kernel above on cfg B (scripts/wgrad_stamps.py) showed the data always there in time (1-3 % of a
+// workgroup's life waiting for HBM) and the life going to the two workgroup barriers per stage (37 %), the burst of
+// loads all 16 waves of a CU issue at the same moment (20 %) and LDS fragment reads (35 %: a 64x16 / 64x32 wave tile
+// re-reads 0.75-1.25 fragments per MFMA).  Here nothing is shared between waves, so there is nothing to synchronise:
+// every wave owns the WHOLE 64x64 output tile for its own 32-row stages of the split (stage s -> wave s mod 4), stages
+// its rows through a private LDS area only to transpose them (ds_read_b64_tr_b16), 0.5 fragments per MFMA, and the
+// waves free-run; the four accumulator sets meet once, through LDS, when the split is done.
+constexpr int PW_THREADS = 256, PW_T = 64, PW_LD = PW_T + 16, PW_ROWS = 32;
+constexpr int PW_WAVE_LDS = 2 * PW_ROWS * PW_LD;   // elements: Y stage + X stage
+constexpr int PW_RED_LD = PW_T + 4;                // padded fp32 row of the final cross-wave sum
+
+// A launch covers up to PW_MAXP problems that share M (the four Linear layers of one encoder layer): the grid is
+// (all their tiles) x (M splits), so one pipeline fill / drain and one slab reduce serve the whole layer.
+constexpr int PW_MAXP = 4;
+struct PwProb {
+  const bf16* Y; const bf16* X;
+  float* slab;       // [splits][N*K]
+  float* bslab;      // [splits][N] or null
+  int ldy, ldx, N, K, tiles_n, tiles_k, tile0;
+};
+struct PwGroup {
+  PwProb pr[PW_MAXP];
+  int nprob, M, ntile, splits, rows_per_split;
+#ifdef IQ_WGRAD_STAMPS
+  unsigned long long* stamps;
+#endif
+};
+
+__global__ __launch_bounds__(PW_THREADS, 3) void wgrad_pw_kernel(const PwGroup g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  bf16* Ys = reinterpret_cast<bf16*>(smem) + wave * PW_WAVE_LDS;
+  bf16* Xs = Ys + PW_ROWS * PW_LD;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);   // the tiles of one split are neighbours on one XCD: re-reads hit its L2
+  const int split = lid / g.ntile, gt = lid % g.ntile;
+  PwProb p = g.pr[0];
+#pragma unroll
+  for (int i = 1; i < PW_MAXP; ++i)
+    if (i < g.nprob && gt >= g.pr[i].tile0) p = g.pr[i];
+  const int tile = gt - p.tile0;
+  // Tiles run along the LONGER side of the output first: where consecutive workgroups spill over to the next XCD the
+  // cut then separates blocks of the wide operand, and only the narrow one is fetched by both L2s.
+  int nt, kt;
+  if (p.tiles_n >= p.tiles_k) { nt = tile / p.tiles_k; kt = tile % p.tiles_k; }
+  else { kt = tile / p.tiles_n; nt = tile % p.tiles_n; }
+  const int n0 = nt * PW_T, k0 = kt * PW_T;
+  const int mbeg = split * g.rows_per_split;
+  const int mend = min(g.M, mbeg + g.rows_per_split);
+  const bool do_bias = p.bslab != nullptr && kt == 0;
+
+  f32x4 acc[4][4], accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+
+  // a load instruction covers 8 rows x 128 B; the 16-lane groups of the LDS write pair rows r and r+4, whose
+  // 160 B-strided images fall on disjoint bank halves
+  const int prow = ((lane >> 4) & 3) + ((lane >> 3) & 1) * 4, pch = lane & 7;
+  // columns past N / K only feed accumulator rows / columns that are never stored: point them at column 0 instead
+  // of predicating the loads.  Rows past the split end must contribute zero (only a split's last stage can be partial).
+  const bf16* yptr = p.Y + (long)prow * p.ldy + (n0 + pch * 8 < p.N ? n0 + pch * 8 : 0);
+  const bf16* xptr = p.X + (long)prow * p.ldx + (k0 + pch * 8 < p.K ? k0 + pch * 8 : 0);
+  const long ystep = 8L * p.ldy, xstep = 8L * p.ldx;
+  bf16x8 ry[4], rx[4];
+  auto gload = [&](int m0) {
+    const bf16* yp = yptr + (long)m0 * p.ldy;
+    const bf16* xp = xptr + (long)m0 * p.ldx;
+    if (m0 + PW_ROWS <= mend) {           // wave-uniform
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ry[j] = *reinterpret_cast<const bf16x8*>(yp + j * ystep);
+        rx[j] = *reinterpret_cast<const bf16x8*>(xp + j * xstep);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bf16x8 vy = {}, vx = {};
+        if (m0 + j * 8 + prow < mend) {
+          vy = *reinterpret_cast<const bf16x8*>(yp + j * ystep);
+          vx = *reinterpret_cast<const bf16x8*>(xp + j * xstep);
+        }
+        ry[j] = vy; rx[j] = vx;
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *reinterpret_cast<bf16x8*>(Ys + (j * 8 + prow) * PW_LD + pch * 8) = ry[j];
+      *reinterpret_cast<bf16x8*>(Xs + (j * 8 + prow) * PW_LD + pch * 8) = rx[j];
+    }
+  };
+
+#ifdef IQ_WGRAD_STAMPS
+  unsigned long long tk_[6] = {0, 0, 0, 0, 0, 0}, tl_, tn_;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_) :: "memory");
+#endif
+  int m = mbeg + wave * PW_ROWS, mnext = m + 4 * PW_ROWS;
+  if (m < mend) {
+    gload(m);
+    lstore();
+    if (mnext < mend) gload(mnext);
+  }
+  IQ_WTICK(0);
+  while (m < mend) {
+    // LDS is in-order within a wave; only keep the compiler from moving reads across the writes of other lanes
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    bf16x8 af[4], bfr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = tr_frag(Ys, PW_LD, 0, i * 16, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = tr_frag(Xs, PW_LD, 0, j * 16, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    IQ_WTICK(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+    }
+    IQ_WTICK(2);
+#ifdef IQ_WGRAD_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IQ_WTICK(3);
+#endif
+    m = mnext; mnext += 4 * PW_ROWS;
+    // the stage lives in registers: its LDS image is overwritten (and the stage after it requested) while the MFMAs
+    // above drain; a wave that finds its data late only stalls itself
+    if (m < mend) {
+      lstore();
+      if (mnext < mend) gload(mnext);
+    }
+    IQ_WTICK(4);
+  }
+#ifdef IQ_WGRAD_STAMPS
+  __syncthreads();
+  IQ_WTICK(5);
+  if (tid == 0 && g.stamps)
+    for (int i = 0; i < 6; ++i) g.stamps[(long)blockIdx.x * 6 + i] = tk_[i];
+#endif
+
+  // ---- sum the four waves' accumulators (two half tiles of 32 n-rows through LDS), write the slab ----------------
+  float* red = reinterpret_cast<float*>(smem);     // [4 waves][32][PW_RED_LD]
+  float* out = p.slab + (long)split * p.N * p.K;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();                               // stage areas (h = 0) / previous half (h = 1) no longer read
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          red[(wave * 32 + ii * 16 + (lane >> 4) * 4 + r) * PW_RED_LD + j * 16 + (lane & 15)] = acc[h * 2 + ii][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int id = tid + c * PW_THREADS;        // 512 float4 = 32 rows x 16
+      const int row = id >> 4, c4 = (id & 15) * 4;
+      f32x4 s = *reinterpret_cast<const f32x4*>(red + row * PW_RED_LD + c4);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) s += *reinterpret_cast<const f32x4*>(red + (w * 32 + row) * PW_RED_LD + c4);
+      const int n = n0 + h * 32 + row, k = k0 + c4;
+      if (n < p.N && k < p.K) *reinterpret_cast<f32x4*>(out + (long)n * p.K + k) = s;   // K % 8 == 0
+    }
+  }
+  if (do_bias) {
+    __syncthreads();
+    // accb: every column of the 16x16 result holds the same row sums; lane&15 == 0 publishes them
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave * 64 + i * 16 + (lane >> 4) * 4 + r] = accb[i][r];
+    }
+    __syncthreads();
+    if (tid < 64 && n0 + tid < p.N)
+      p.bslab[(long)split * p.N + n0 + tid] = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+  }
+}
+
+// out[i] (+)= sum_s slab[s][i] for up to 2*PW_MAXP segments (weights and biases of a group) in ONE launch.
+// Block = 64 float4 columns x 4 split slices (coalesced 1 KiB rows, 4x the loads in flight of a one-thread-per-column
+// loop), slices combined through LDS in fixed order: bit-reproducible.
+struct RedSeg { const float* slab; float* out; long n; int blk0; };
+struct RedGroup { RedSeg s[2 * PW_MAXP]; int nseg, splits, accumulate; };
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedGroup g) {
   __shared__ f32x4 part[4][64];
-  const long nblk_w = (n + 255) / 256;
-  if ((long)blockIdx.x >= nblk_w) { slab = bslab; n = nb; out = bout; }
-  const long blk = (long)blockIdx.x >= nblk_w ? (long)blockIdx.x - nblk_w : (long)blockIdx.x;
+  RedSeg sg = g.s[0];
+#pragma unroll
+  for (int i = 1; i < 2 * PW_MAXP; ++i)
+    if (i < g.nseg && (int)blockIdx.x >= g.s[i].blk0) sg = g.s[i];
+  const float* __restrict__ slab = sg.slab;
+  float* __restrict__ out = sg.out;
+  const long n = sg.n;
+  const long blk = (long)blockIdx.x - sg.blk0;
+  const int splits = g.splits, accumulate = g.accumulate;
   const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const long i = (blk * 64 + col) * 4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -187,11 +416,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-struct WgradPlan { int tk, tiles_n, tiles_k, splits, rows_per_split; };
+struct WgradPlan { int tk, mc, tiles_n, tiles_k, splits, rows_per_split; };
 
+// shared-tile kernel (one problem)
 inline WgradPlan wgrad_plan(int M, int N, int K) {
   WgradPlan w;
   w.tk = (K % 128 == 0 || K > 512) ? 128 : 64;
+  static const int mc_env = getenv("IQ_WGRAD_MC") ? atoi(getenv("IQ_WGRAD_MC")) : 0;   // diagnostic override
+  w.mc = mc_env == 64 ? 64 : 128;
+  const int MC = w.mc;
   w.tiles_n = (N + TN - 1) / TN;
   w.tiles_k = (K + w.tk - 1) / w.tk;
   const int tiles = w.tiles_n * w.tiles_k;
@@ -207,43 +440,177 @@ inline WgradPlan wgrad_plan(int M, int N, int K) {
   return w;
 }
 
+// Wave-private 64x64 tiles while the outputs are small (operand re-reads grow as N*K/32 per row and stay in L2);
+// the shared 128x128 tiles for the large, MFMA-bound shapes (ViT-Base).  IQ_WGRAD_KERNEL=shared|pw overrides.
+inline bool pw_eligible(int N, int K) {
+  static const char* force = getenv("IQ_WGRAD_KERNEL");
+  return force ? (force[0] == 'p') : ((long)N * K <= 512 * 1024);
+}
+inline size_t pad4(size_t v) { return (v + 3) / 4 * 4; }
+
+struct PwPlan { int ntile, splits, rows_per_split; size_t floats; };
+inline PwPlan pw_plan(const iq_wgrad_problem_t* pr, int nprob, int M) {
+  PwPlan w;
+  w.ntile = 0;
+  for (int i = 0; i < nprob; ++i) w.ntile += ((pr[i].N + PW_T - 1) / PW_T) * ((pr[i].K + PW_T - 1) / PW_T);
+  int splits = 768 / w.ntile;                       // three 4-wave workgroups per CU, filled once
+  const int max_splits = (M + 255) / 256;           // at least two stages per wave
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int unit = 4 * PW_ROWS;
+  int rps = (M + splits - 1) / splits;
+  rps = ((rps + unit - 1) / unit) * unit;
+  w.rows_per_split = rps;
+  w.splits = (M + rps - 1) / rps;
+  w.floats = 0;
+  for (int i = 0; i < nprob; ++i) w.floats += (size_t)w.splits * (pad4((size_t)pr[i].N * pr[i].K) + pad4(pr[i].N));
+  return w;
+}
+inline bool group_is_pw(const iq_wgrad_problem_t* pr, int nprob) {
+  if (nprob < 1 || nprob > PW_MAXP) return false;
+  for (int i = 0; i < nprob; ++i)
+    if (!pw_eligible(pr[i].N, pr[i].K)) return false;
+  return true;
+}
+inline size_t shared_ws_floats(int M, int N, int K) {
+  const WgradPlan w = wgrad_plan(M, N, K);
+  return (size_t)w.splits * (pad4((size_t)N * K) + pad4(N));
+}
+
+#ifdef IQ_WGRAD_STAMPS
+unsigned long long* g_wstamps = nullptr;
+#endif
+
+int launch_reduce(const RedGroup& rg, int nblk, hipStream_t st) {
+  wgrad_reduce_kernel<<<nblk, 256, 0, st>>>(rg);
+  return IQ_OK;
+}
+
+int wgrad_shared_one(const iq_wgrad_problem_t& pb, int M, float* ws, int accumulate, hipStream_t st) {
+  const int N = pb.N, K = pb.K;
+  const WgradPlan w = wgrad_plan(M, N, K);
+  WgradParams q;
+  q.Y = (const bf16*)pb.dY; q.X = (const bf16*)pb.X; q.ldy = pb.ldy; q.ldx = pb.ldx; q.M = M; q.N = N; q.K = K;
+  q.slab = ws;
+  q.bslab = pb.dbias ? ws + (size_t)w.splits * pad4((size_t)N * K) : nullptr;
+  q.tiles_n = w.tiles_n; q.tiles_k = w.tiles_k; q.splits = w.splits; q.rows_per_split = w.rows_per_split;
+#ifdef IQ_WGRAD_STAMPS
+  q.stamps = g_wstamps;
+#endif
+  const int grid = w.tiles_n * w.tiles_k * w.splits;
+  const size_t lds = (size_t)w.mc * (YLD + w.tk + 16) * 2;
+#define IQ_WG_LAUNCH(TK_, MC_)                                                                                   \
+  do {                                                                                                           \
+    auto k = wgrad_kernel<TK_, MC_>;                                                                             \
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    k<<<grid, WG_THREADS, lds, st>>>(q);                                                                         \
+  } while (0)
+  if (w.tk == 128) { if (w.mc == 128) IQ_WG_LAUNCH(128, 128); else IQ_WG_LAUNCH(128, 64); }
+  else { if (w.mc == 128) IQ_WG_LAUNCH(64, 128); else IQ_WG_LAUNCH(64, 64); }
+#undef IQ_WG_LAUNCH
+  RedGroup rg;
+  memset(&rg, 0, sizeof(rg));
+  const long n = (long)N * K;
+  rg.s[0] = RedSeg{q.slab, pb.dW, n, 0};
+  int nblk = (int)((n + 255) / 256);
+  rg.nseg = 1;
+  if (pb.dbias) { rg.s[1] = RedSeg{q.bslab, pb.dbias, (long)N, nblk}; nblk += (N + 255) / 256; rg.nseg = 2; }
+  rg.splits = w.splits; rg.accumulate = accumulate;
+  return launch_reduce(rg, nblk, st);
+}
+
 }  // namespace
+
+#ifdef IQ_WGRAD_STAMPS
+extern "C" void iq_debug_set_wgrad_stamps(unsigned long long* p) { g_wstamps = p; }
+#endif
+
+extern "C" size_t iq_wgrad_grouped_ws_bytes(const iq_wgrad_problem_t* probs, int nprob, int M) {
+  if (!probs || nprob <= 0 || M <= 0) return 0;
+  if (group_is_pw(probs, nprob)) return pw_plan(probs, nprob, M).floats * sizeof(float);
+  size_t mx = 0;                                    // run one at a time, sharing the area
+  for (int i = 0; i < nprob; ++i) {
+    const size_t b = pw_eligible(probs[i].N, probs[i].K) ? pw_plan(probs + i, 1, M).floats
+                                                          : shared_ws_floats(M, probs[i].N, probs[i].K);
+    if (b > mx) mx = b;
+  }
+  return mx * sizeof(float);
+}
+
+extern "C" int iq_gemm_bf16_wgrad_grouped(const iq_wgrad_problem_t* probs, int nprob, int M, float* ws, size_t ws_bytes,
+                                          int accumulate, iq_stream_t stream) {
+  if (nprob <= 0) return IQ_OK;
+  if (!probs || !ws || M <= 0) return IQ_ERR_ARG;
+  for (int i = 0; i < nprob; ++i) {
+    const iq_wgrad_problem_t& b = probs[i];
+    if (b.N <= 0 || b.K <= 0 || !b.dY || !b.X || !b.dW) return IQ_ERR_ARG;
+    if ((b.N % 8) || (b.K % 8) || (b.ldy % 8) || (b.ldx % 8)) return IQ_ERR_UNSUPPORTED;
+    if (((uintptr_t)b.dW & 15) != 0) return IQ_ERR_ARG;
+  }
+  if (ws_bytes < iq_wgrad_grouped_ws_bytes(probs, nprob, M)) return IQ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  IQ_PROF(IQ_FAM_WGRAD, st);
+  if (!group_is_pw(probs, nprob)) {
+    for (int i = 0; i < nprob; ++i) {
+      int rc;
+      if (pw_eligible(probs[i].N, probs[i].K)) {
+        rc = iq_gemm_bf16_wgrad_grouped(probs + i, 1, M, ws, ws_bytes, accumulate, stream);
+      } else {
+        rc = wgrad_shared_one(probs[i], M, ws, accumulate, st);
+      }
+      if (rc != IQ_OK) return rc;
+    }
+    return iq_launch_status();
+  }
+  const PwPlan w = pw_plan(probs, nprob, M);
+  PwGroup g;
+  RedGroup rg;
+  memset(&g, 0, sizeof(g));
+  memset(&rg, 0, sizeof(rg));
+  g.nprob = nprob; g.M = M; g.ntile = w.ntile; g.splits = w.splits; g.rows_per_split = w.rows_per_split;
+#ifdef IQ_WGRAD_STAMPS
+  g.stamps = g_wstamps;
+#endif
+  float* cur = ws;
+  int tile0 = 0, nblk = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const iq_wgrad_problem_t& b = probs[i];
+    PwProb& q = g.pr[i];
+    q.Y = (const bf16*)b.dY; q.X = (const bf16*)b.X; q.ldy = b.ldy; q.ldx = b.ldx; q.N = b.N; q.K = b.K;
+    q.tiles_n = (b.N + PW_T - 1) / PW_T;
+    q.tiles_k = (b.K + PW_T - 1) / PW_T;
+    q.tile0 = tile0;
+    tile0 += q.tiles_n * q.tiles_k;
+    const long n = (long)b.N * b.K;
+    q.slab = cur; cur += (size_t)w.splits * pad4((size_t)n);
+    rg.s[rg.nseg++] = RedSeg{q.slab, b.dW, n, nblk};
+    nblk += (int)((n + 255) / 256);
+    if (b.dbias) {
+      q.bslab = cur; cur += (size_t)w.splits * pad4(b.N);
+      rg.s[rg.nseg++] = RedSeg{q.bslab, b.dbias, (long)b.N, nblk};
+      nblk += (b.N + 255) / 256;
+    }
+  }
+  rg.splits = w.splits; rg.accumulate = accumulate;
+  const size_t lds_pw = (size_t)4 * PW_WAVE_LDS * 2;   // 40 KiB >= 4 x 32 x PW_RED_LD x 4 B of the final sum
+  static_assert(4 * PW_WAVE_LDS * 2 >= 4 * 32 * PW_RED_LD * 4, "reduction area must fit the stage areas");
+  wgrad_pw_kernel<<<w.ntile * w.splits, PW_THREADS, lds_pw, st>>>(g);
+  launch_reduce(rg, nblk, st);
+  return iq_launch_status();
+}
 
 extern "C" size_t iq_wgrad_ws_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  WgradPlan w = wgrad_plan(M, N, K);
-  size_t nk = ((size_t)N * K + 3) / 4 * 4;
-  return ((size_t)w.splits * nk + (size_t)w.splits * ((N + 3) / 4 * 4)) * sizeof(float);
+  iq_wgrad_problem_t b;
+  memset(&b, 0, sizeof(b));
+  b.N = N; b.K = K;
+  return iq_wgrad_grouped_ws_bytes(&b, 1, M);
 }
 
 extern "C" int iq_gemm_bf16_wgrad(const void* dY, int ldy, const void* X, int ldx, float* dW, float* dbias, int M,
                                   int N, int K, float* ws, size_t ws_bytes, int accumulate, iq_stream_t stream) {
   if (N <= 0 || K <= 0) return IQ_OK;
-  if (!dY || !X || !dW || !ws || M <= 0) return IQ_ERR_ARG;
-  if ((N % 8) || (K % 8) || (ldy % 8) || (ldx % 8)) return IQ_ERR_UNSUPPORTED;
-  if (ws_bytes < iq_wgrad_ws_bytes(M, N, K)) return IQ_ERR_ARG;
-  if (((uintptr_t)dW & 15) != 0) return IQ_ERR_ARG;
-  WgradPlan w = wgrad_plan(M, N, K);
-  WgradParams p;
-  p.Y = (const bf16*)dY; p.X = (const bf16*)X; p.ldy = ldy; p.ldx = ldx; p.M = M; p.N = N; p.K = K;
-  const size_t nk = ((size_t)N * K + 3) / 4 * 4;
-  p.slab = ws;
-  p.bslab = dbias ? ws + (size_t)w.splits * nk : nullptr;
-  p.tiles_n = w.tiles_n; p.tiles_k = w.tiles_k; p.splits = w.splits; p.rows_per_split = w.rows_per_split;
-  hipStream_t st = (hipStream_t)stream;
-  IQ_PROF(IQ_FAM_WGRAD, st);
-  const int grid = w.tiles_n * w.tiles_k * w.splits;
-  // slab stride must equal N*K for the reduce kernel; nk padding only affects the bias slab offset
-  WgradParams q = p;
-  if (w.tk == 128) {
-    const size_t lds = (size_t)MC * (YLD + 128 + 16) * 2;
-    wgrad_kernel<128><<<grid, WG_THREADS, lds, st>>>(q);
-  } else {
-    const size_t lds = (size_t)MC * (YLD + 64 + 16) * 2;
-    wgrad_kernel<64><<<grid, WG_THREADS, lds, st>>>(q);
-  }
-  const long n = (long)N * K;
-  const int nblk_w = (int)((n + 255) / 256), nblk_b = dbias ? (N + 255) / 256 : 0;
-  wgrad_reduce_kernel<<<nblk_w + nblk_b, 256, 0, st>>>(p.slab, n, w.splits, dW, p.bslab, (long)N, dbias, accumulate);
-  return iq_launch_status();
+  iq_wgrad_problem_t b;
+  b.dY = dY; b.ldy = ldy; b.X = X; b.ldx = ldx; b.dW = dW; b.dbias = dbias; b.N = N; b.K = K;
+  return iq_gemm_bf16_wgrad_grouped(&b, 1, M, ws, ws_bytes, accumulate, stream);
 }

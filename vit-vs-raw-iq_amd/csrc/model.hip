@@ -142,10 +142,6 @@ struct iq_model {
   const float* pe = nullptr;
   unsigned char* shadow = nullptr;
   std::string err;
-  // side stream for the weight-gradient GEMMs (off the dX critical path) + fork/join events; created at bind
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_prod[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_done[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
   uint64_t last_seed = 0;   // seed of the last training forward; backward regenerates the same masks
   bool last_tr = false;     // whether the last forward applied dropout
 
@@ -214,10 +210,15 @@ WsPlan plan_ws(const iq_model* m, int B) {
   w.demb = take(MT * D * 2);
   size_t wb = 0;
   auto mx = [&](size_t v) { if (v > wb) wb = v; };
-  mx(iq_wgrad_ws_bytes((int)M, (int)D, (int)F));
-  mx(iq_wgrad_ws_bytes((int)M, (int)F, (int)D));
-  mx(iq_wgrad_ws_bytes((int)M, (int)D, (int)D));
-  mx(iq_wgrad_ws_bytes((int)M, (int)(3 * D), (int)D));
+  {
+    iq_wgrad_problem_t g[4];
+    memset(g, 0, sizeof(g));
+    g[0].N = (int)D; g[0].K = (int)F;
+    g[1].N = (int)F; g[1].K = (int)D;
+    g[2].N = (int)D; g[2].K = (int)D;
+    g[3].N = (int)(3 * D); g[3].K = (int)D;
+    mx(iq_wgrad_grouped_ws_bytes(g, 4, (int)M));
+  }
   mx(iq_wgrad_ws_bytes((int)MT, (int)D, m->Ppad));
   w.wgrad_ws_bytes = wb;
   w.wgrad_ws = take(wb);
@@ -354,11 +355,6 @@ extern "C" int iq_model_create(const iq_model_cfg_t* cfg, iq_model_t** out) {
 
 extern "C" void iq_model_destroy(iq_model_t* m) {
   if (!m) return;
-  if (m->side) {
-    (void)hipStreamDestroy(m->side);
-    (void)hipEventDestroy(m->ev_fork); (void)hipEventDestroy(m->ev_join);
-    for (int i = 0; i < 4; ++i) { (void)hipEventDestroy(m->ev_prod[i]); (void)hipEventDestroy(m->ev_done[0][i]); (void)hipEventDestroy(m->ev_done[1][i]); }
-  }
   delete m;
 }
 extern "C" const char* iq_model_last_error(const iq_model_t* m) { return m ? m->err.c_str() : "null model"; }
@@ -387,13 +383,6 @@ extern "C" int iq_model_bind(iq_model_t* m, float* params, float* grads, const f
   if (!params || !pe || !shadow) return fail(m, IQ_ERR_ARG, "bind: params, pe and shadow are required");
   if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)shadow) & 255) return fail(m, IQ_ERR_ARG, "bind: buffers must be 256 B aligned");
   m->params = params; m->grads = grads; m->pe = pe; m->shadow = (unsigned char*)shadow;
-  if (!m->side) {
-    bool ok = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) == hipSuccess;
-    auto mk = [&](hipEvent_t* e) { ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
-    mk(&m->ev_fork); mk(&m->ev_join);
-    for (int i = 0; i < 4; ++i) { mk(&m->ev_prod[i]); mk(&m->ev_done[0][i]); mk(&m->ev_done[1][i]); }
-    if (!ok) return fail(m, IQ_ERR_LAUNCH, "bind: creating the side stream / events failed");
-  }
   if (m->table_uploaded_to != shadow && !m->ttab.empty()) {
     // one small synchronous copy per (re)binding of the shadow buffer; never on the step path
     if (hipMemcpy(m->shadow + m->sh_table, m->ttab.data(), m->ttab.size() * sizeof(TransDesc), hipMemcpyHostToDevice) != hipSuccess)
@@ -535,80 +524,43 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
     }
     if (denc) f32_into_bf16_kernel<<<blocks_for((size_t)M * D / 8), 256, 0, st>>>(denc, (bf16*)(ws + w.gA), (size_t)M * D / 8, dlogits ? 1 : 0);
   }
-  // Weight gradients run on a side stream: they are off the dX critical path, and a wgrad co-resident with the
-  // dgrad / LayerNorm / attention kernels of the chain fills the phases in which those leave a CU's MFMA pipe
-  // or its memory pipe idle.  Producer events order each wgrad after the kernel that writes its dY; "done"
-  // events order the NEXT layer's overwrite of that buffer after the wgrad that still reads it (one layer of
-  // slack).  Every call forks at entry and joins at exit, so callers (all-reduce, optimizer) see one stream.
-  // Measured on cfg B: no gain (8.67 ms two streams vs 8.44 ms one), so the side stream is opt-in.
-  static const bool one_stream = getenv("IQ_BWD_TWO_STREAMS") == nullptr;
-  hipStream_t s2 = one_stream ? st : m->side;
-  iq_stream_t stream2 = (iq_stream_t)s2;
-  bool forked = false, pending[2][4] = {{false, false, false, false}, {false, false, false, false}};
-  auto produced = [&](int k) {                       // s1 just wrote the dY of wgrad k
-    if (one_stream) return;
-    if (!forked) forked = true;
-    (void)hipEventRecord(m->ev_prod[k], st);
-    (void)hipStreamWaitEvent(s2, m->ev_prod[k], 0);
-  };
-  auto done = [&](int par, int k) {                  // s2 finished wgrad k of a layer with parity par
-    if (one_stream) return;
-    (void)hipEventRecord(m->ev_done[par][k], s2);
-    pending[par][k] = true;
-  };
-  auto before_overwrite = [&](int par, int k) {      // s1 is about to overwrite the dY wgrad k (previous layer) read
-    if (one_stream || !pending[par][k]) return;
-    (void)hipStreamWaitEvent(st, m->ev_done[par][k], 0);
-    pending[par][k] = false;
-  };
+  // The four weight gradients of a layer are independent of its dX chain and of each other, and their dY operands
+  // (gY|gZ, gH, gY1|gZ1, gQKV) all stay live until the next layer overwrites them: they run as ONE grouped launch
+  // (+ one slab reduce) at the end of the layer instead of four (+ four) in between -- one pipeline fill / drain,
+  // 3x fewer slab bytes.  (A side stream for them was measured twice: no gain, 7.00 vs 6.79 ms/step.)
   for (int sidx = (stage_hi > Lr ? Lr : stage_hi); sidx >= 1 && sidx >= stage_lo; --sidx) {
     const int l = sidx - 1;
-    const int par = l & 1, prev = par ^ 1;
     const LayerOff& o = m->L[l];
     const WsPlan::L& a = w.layers[l];
     const unsigned char* xin = l == 0 ? ws + w.x0 : ws + w.layers[l - 1].x2;
     iq_epilogue_t e;
     // norm2 backward (+ regenerated dropout2 mask)
     const iq_dropout_t dr2 = m->bwd_site(3 + 3 * l, step_dev, tr);
-    before_overwrite(prev, 0);
     IQ_TRY(iq_ln_bwd(ws + w.gA, ws + a.z2, (const float*)(ws + a.mean2), (const float*)(ws + a.rstd2), P + o.g2,
                      ws + w.gZ, ws + w.gY, &dr2, G + o.g2, G + o.be2, lws, accumulate, M, D, stream), "norm2 bwd");
     const unsigned char* dO2 = tr ? ws + w.gY : ws + w.gZ;
-    produced(0);
-    IQ_TRY(iq_gemm_bf16_wgrad(dO2, D, ws + a.hid, F, G + o.w2, G + o.b2, M, D, F, wws, w.wgrad_ws_bytes, accumulate, stream2), "ffn2 wgrad");
-    done(par, 0);
     memset(&e, 0, sizeof(e));
     e.gate = ws + a.hid; e.ldg = F; e.gate_scale = dscale;
-    before_overwrite(prev, 1);
     IQ_TRY(iq_gemm_bf16_nt(dO2, D, m->sht(o.t_w2), D, ws + w.gH, F, M, F, D, &e, stream), "ffn2 dgrad");
-    produced(1);
-    IQ_TRY(iq_gemm_bf16_wgrad(ws + w.gH, F, ws + a.x1, D, G + o.w1, G + o.b1, M, F, D, wws, w.wgrad_ws_bytes, accumulate, stream2), "ffn1 wgrad");
-    done(par, 1);
     memset(&e, 0, sizeof(e));
     e.residual = ws + w.gZ; e.ldr = D;
     IQ_TRY(iq_gemm_bf16_nt(ws + w.gH, F, m->sht(o.t_w1), F, ws + w.gB, D, M, D, F, &e, stream), "ffn1 dgrad");
     // norm1 backward (+ dropout1 mask)
     const iq_dropout_t dr1 = m->bwd_site(1 + 3 * l, step_dev, tr);
-    before_overwrite(prev, 2);
     IQ_TRY(iq_ln_bwd(ws + w.gB, ws + a.z1, (const float*)(ws + a.mean1), (const float*)(ws + a.rstd1), P + o.g1,
                      ws + w.gZ1, ws + w.gY1, &dr1, G + o.g1, G + o.be1, lws, accumulate, M, D, stream), "norm1 bwd");
     const unsigned char* dAo = tr ? ws + w.gY1 : ws + w.gZ1;
-    produced(2);
-    IQ_TRY(iq_gemm_bf16_wgrad(dAo, D, ws + a.att, D, G + o.wo, G + o.bo, M, D, D, wws, w.wgrad_ws_bytes, accumulate, stream2), "out-proj wgrad");
-    done(par, 2);
     IQ_TRY(iq_gemm_bf16_nt(dAo, D, m->sht(o.t_wo), D, ws + w.gAtt, D, M, D, D, nullptr, stream), "out-proj dgrad");
-    before_overwrite(prev, 3);
     IQ_TRY(iq_attn_bwd(ws + a.qkv, ws + a.att, ws + w.gAtt, (const float*)(ws + a.lse), ws + w.gQKV, B, S, H, m->dh, stream), "attention bwd");
-    produced(3);
-    IQ_TRY(iq_gemm_bf16_wgrad(ws + w.gQKV, 3 * D, xin, D, G + o.wqkv, G + o.bqkv, M, 3 * D, D, wws, w.wgrad_ws_bytes, accumulate, stream2), "qkv wgrad");
-    done(par, 3);
     memset(&e, 0, sizeof(e));
     e.residual = ws + w.gZ1; e.ldr = D;
     IQ_TRY(iq_gemm_bf16_nt(ws + w.gQKV, 3 * D, m->sht(o.t_wqkv), 3 * D, ws + w.gA, D, M, D, 3 * D, &e, stream), "qkv dgrad");
-  }
-  if (forked) {                                      // join: everything the side stream did is visible on s1
-    (void)hipEventRecord(m->ev_join, s2);
-    (void)hipStreamWaitEvent(st, m->ev_join, 0);
+    const iq_wgrad_problem_t wg[4] = {
+        {dO2, D, ws + a.hid, F, G + o.w2, G + o.b2, D, F},                 // ffn.linear2
+        {ws + w.gH, F, ws + a.x1, D, G + o.w1, G + o.b1, F, D},            // ffn.linear1
+        {dAo, D, ws + a.att, D, G + o.wo, G + o.bo, D, D},                 // attention.w_concat
+        {ws + w.gQKV, 3 * D, xin, D, G + o.wqkv, G + o.bqkv, 3 * D, D}};   // attention.w_q|w_k|w_v
+    IQ_TRY(iq_gemm_bf16_wgrad_grouped(wg, 4, M, wws, w.wgrad_ws_bytes, accumulate, stream), "layer weight gradients");
   }
   if (stage_lo == 0) {
     const iq_dropout_t dr0 = m->bwd_site(0, step_dev, tr);
