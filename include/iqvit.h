@@ -94,9 +94,11 @@ typedef struct iq_wgrad_problem {
   float* dbias;   /* fp32 [N] or NULL */
   int N, K;
 } iq_wgrad_problem_t;
-size_t iq_wgrad_grouped_ws_bytes(const iq_wgrad_problem_t* probs, int nprob, int M);
+/* max_workgroups: 0 = fill the GPU once (768 workgroups); a smaller budget leaves CU slots free for kernels of
+ * another stream (the model's backward overlaps a layer's weight gradients with the next layer's dX chain). */
+size_t iq_wgrad_grouped_ws_bytes(const iq_wgrad_problem_t* probs, int nprob, int M, int max_workgroups);
 int iq_gemm_bf16_wgrad_grouped(const iq_wgrad_problem_t* probs, int nprob, int M, float* ws, size_t ws_bytes,
-                               int accumulate, iq_stream_t stream);
+                               int accumulate, int max_workgroups, iq_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Scaled-dot-product attention core, softmax(Q K^T / sqrt(dh)) V per (frame, head), no mask,

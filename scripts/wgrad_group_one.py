@@ -7,6 +7,7 @@ import vit_vs_raw_iq_amd._native as N
 L = N.lib(); d = torch.device("cuda:0")
 M = 50432; D, F = 192, 768
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+budget = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 shapes = [(D, F), (F, D), (D, D), (3 * D, D)]
 probs = (N.WgradProblem * 4)(); keep = []
 byt = 0
@@ -16,15 +17,15 @@ for i, (n, k) in enumerate(shapes):
     probs[i].dY = dY.data_ptr(); probs[i].ldy = n; probs[i].X = X.data_ptr(); probs[i].ldx = k
     probs[i].dW = dW.data_ptr(); probs[i].dbias = db.data_ptr(); probs[i].N = n; probs[i].K = k
     byt += 2 * M * (n + k) + 4 * n * k
-nb = L.iq_wgrad_grouped_ws_bytes(probs, 4, M); ws = torch.empty(nb, dtype=torch.uint8, device=d)
+nb = L.iq_wgrad_grouped_ws_bytes(probs, 4, M, budget); ws = torch.empty(nb, dtype=torch.uint8, device=d)
 st = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
-    L.iq_gemm_bf16_wgrad_grouped(probs, 4, M, ws.data_ptr(), nb, 0, st)
+    L.iq_gemm_bf16_wgrad_grouped(probs, 4, M, ws.data_ptr(), nb, 0, budget, st)
 torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record()
 for _ in range(reps):
-    L.iq_gemm_bf16_wgrad_grouped(probs, 4, M, ws.data_ptr(), nb, 0, st)
+    L.iq_gemm_bf16_wgrad_grouped(probs, 4, M, ws.data_ptr(), nb, 0, budget, st)
 b.record(); torch.cuda.synchronize()
 us = a.elapsed_time(b) / reps * 1e3
 print(f"grouped layer wgrad: {us:.1f} us  algorithmic {byt / 1e6:.1f} MB -> {byt / us / 1e3:.0f} GB/s  slab ws {nb / 1e6:.1f} MB")

@@ -259,12 +259,13 @@ def test_wgrad(L, M, N_, K):
     close_f32(dW, 2 * ref, "dW acc")
 
 
-@pytest.mark.parametrize("M,shapes", [
-    (3940, [(192, 768), (768, 192), (192, 192), (576, 192)]),     # one ViT-Tiny encoder layer
-    (1000, [(128, 256), (40, 72)]),                               # partial tiles, two problems
-    (515, [(64, 64), (1024, 768), (72, 64)]),                     # a large member: falls back to one launch per problem
+@pytest.mark.parametrize("M,shapes,budget", [
+    (3940, [(192, 768), (768, 192), (192, 192), (576, 192)], 0),   # one ViT-Tiny encoder layer
+    (3940, [(192, 768), (768, 192), (192, 192), (576, 192)], 256), # same with a workgroup budget (overlapped backward)
+    (1000, [(128, 256), (40, 72)], 0),                             # partial tiles, two problems
+    (515, [(64, 64), (1024, 768), (72, 64)], 0),                   # a large member: falls back to one launch per problem
 ])
-def test_wgrad_grouped(L, M, shapes):
+def test_wgrad_grouped(L, M, shapes, budget):
     """Several weight gradients sharing M in one launch == each one alone (fp64 reference), with and without accumulate."""
     N = _N()
     g = torch.Generator(device="cuda").manual_seed(M)
@@ -280,17 +281,17 @@ def test_wgrad_grouped(L, M, shapes):
         probs[i].dW = dW.data_ptr(); probs[i].dbias = db.data_ptr() if db is not None else None
         probs[i].N = n; probs[i].K = k
         refs.append((dY.double().t() @ X.double(), dY.double().sum(0)))
-    nbytes = L.iq_wgrad_grouped_ws_bytes(probs, len(shapes), M)
+    nbytes = L.iq_wgrad_grouped_ws_bytes(probs, len(shapes), M, budget)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
-    N.check(L.iq_gemm_bf16_wgrad_grouped(probs, len(shapes), M, ws.data_ptr(), nbytes, 0, stream()), "grouped")
+    N.check(L.iq_gemm_bf16_wgrad_grouped(probs, len(shapes), M, ws.data_ptr(), nbytes, 0, budget, stream()), "grouped")
     for (dY, X, dW, db), (rw, rb) in zip(keep, refs):
         close_f32(dW, rw, "dW")
         if db is not None:
             close_f32(db, rb, "db")
-    N.check(L.iq_gemm_bf16_wgrad_grouped(probs, len(shapes), M, ws.data_ptr(), nbytes, 1, stream()), "grouped acc")
+    N.check(L.iq_gemm_bf16_wgrad_grouped(probs, len(shapes), M, ws.data_ptr(), nbytes, 1, budget, stream()), "grouped acc")
     for (dY, X, dW, db), (rw, rb) in zip(keep, refs):
         close_f32(dW, 2 * rw, "dW acc")
-    assert L.iq_gemm_bf16_wgrad_grouped(probs, len(shapes), M, ws.data_ptr(), nbytes - 1, 0, stream()) != 0   # ws too small
+    assert L.iq_gemm_bf16_wgrad_grouped(probs, len(shapes), M, ws.data_ptr(), nbytes - 1, 0, budget, stream()) != 0   # ws too small
 
 
 def test_wgrad_exact_integers(L):

@@ -53,8 +53,8 @@ SIGNATURES = {
     "iq_gemm_bf16_nt": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, C.POINTER(Epilogue), _P]),
     "iq_wgrad_ws_bytes": (_Z, [_I, _I, _I]),
     "iq_gemm_bf16_wgrad": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _Z, _I, _P]),
-    "iq_wgrad_grouped_ws_bytes": (_Z, [_P, _I, _I]),
-    "iq_gemm_bf16_wgrad_grouped": (_I, [_P, _I, _I, _P, _Z, _I, _P]),
+    "iq_wgrad_grouped_ws_bytes": (_Z, [_P, _I, _I, _I]),
+    "iq_gemm_bf16_wgrad_grouped": (_I, [_P, _I, _I, _P, _Z, _I, _I, _P]),
     "iq_attn_supported": (_I, [_I, _I]),
     "iq_attn_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "iq_attn_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -449,11 +449,14 @@ inline bool pw_eligible(int N, int K) {
 inline size_t pad4(size_t v) { return (v + 3) / 4 * 4; }
 
 struct PwPlan { int ntile, splits, rows_per_split; size_t floats; };
-inline PwPlan pw_plan(const iq_wgrad_problem_t* pr, int nprob, int M) {
+inline PwPlan pw_plan(const iq_wgrad_problem_t* pr, int nprob, int M, int max_wgs) {
   PwPlan w;
   w.ntile = 0;
   for (int i = 0; i < nprob; ++i) w.ntile += ((pr[i].N + PW_T - 1) / PW_T) * ((pr[i].K + PW_T - 1) / PW_T);
-  int splits = 768 / w.ntile;                       // three 4-wave workgroups per CU, filled once
+  // three 4-wave workgroups per CU, filled once -- or the caller's smaller budget when the launch is meant to
+  // share the CUs with another stream's kernels
+  const int slots = (max_wgs > 0 && max_wgs < 768) ? max_wgs : 768;
+  int splits = slots / w.ntile;
   const int max_splits = (M + 255) / 256;           // at least two stages per wave
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -525,12 +528,12 @@ int wgrad_shared_one(const iq_wgrad_problem_t& pb, int M, float* ws, int accumul
 extern "C" void iq_debug_set_wgrad_stamps(unsigned long long* p) { g_wstamps = p; }
 #endif
 
-extern "C" size_t iq_wgrad_grouped_ws_bytes(const iq_wgrad_problem_t* probs, int nprob, int M) {
+extern "C" size_t iq_wgrad_grouped_ws_bytes(const iq_wgrad_problem_t* probs, int nprob, int M, int max_workgroups) {
   if (!probs || nprob <= 0 || M <= 0) return 0;
-  if (group_is_pw(probs, nprob)) return pw_plan(probs, nprob, M).floats * sizeof(float);
+  if (group_is_pw(probs, nprob)) return pw_plan(probs, nprob, M, max_workgroups).floats * sizeof(float);
   size_t mx = 0;                                    // run one at a time, sharing the area
   for (int i = 0; i < nprob; ++i) {
-    const size_t b = pw_eligible(probs[i].N, probs[i].K) ? pw_plan(probs + i, 1, M).floats
+    const size_t b = pw_eligible(probs[i].N, probs[i].K) ? pw_plan(probs + i, 1, M, max_workgroups).floats
                                                           : shared_ws_floats(M, probs[i].N, probs[i].K);
     if (b > mx) mx = b;
   }
@@ -538,7 +541,7 @@ extern "C" size_t iq_wgrad_grouped_ws_bytes(const iq_wgrad_problem_t* probs, int
 }
 
 extern "C" int iq_gemm_bf16_wgrad_grouped(const iq_wgrad_problem_t* probs, int nprob, int M, float* ws, size_t ws_bytes,
-                                          int accumulate, iq_stream_t stream) {
+                                          int accumulate, int max_workgroups, iq_stream_t stream) {
   if (nprob <= 0) return IQ_OK;
   if (!probs || !ws || M <= 0) return IQ_ERR_ARG;
   for (int i = 0; i < nprob; ++i) {
@@ -547,14 +550,14 @@ extern "C" int iq_gemm_bf16_wgrad_grouped(const iq_wgrad_problem_t* probs, int n
     if ((b.N % 8) || (b.K % 8) || (b.ldy % 8) || (b.ldx % 8)) return IQ_ERR_UNSUPPORTED;
     if (((uintptr_t)b.dW & 15) != 0) return IQ_ERR_ARG;
   }
-  if (ws_bytes < iq_wgrad_grouped_ws_bytes(probs, nprob, M)) return IQ_ERR_ARG;
+  if (ws_bytes < iq_wgrad_grouped_ws_bytes(probs, nprob, M, max_workgroups)) return IQ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   IQ_PROF(IQ_FAM_WGRAD, st);
   if (!group_is_pw(probs, nprob)) {
     for (int i = 0; i < nprob; ++i) {
       int rc;
       if (pw_eligible(probs[i].N, probs[i].K)) {
-        rc = iq_gemm_bf16_wgrad_grouped(probs + i, 1, M, ws, ws_bytes, accumulate, stream);
+        rc = iq_gemm_bf16_wgrad_grouped(probs + i, 1, M, ws, ws_bytes, accumulate, max_workgroups, stream);
       } else {
         rc = wgrad_shared_one(probs[i], M, ws, accumulate, st);
       }
@@ -562,7 +565,7 @@ extern "C" int iq_gemm_bf16_wgrad_grouped(const iq_wgrad_problem_t* probs, int n
     }
     return iq_launch_status();
   }
-  const PwPlan w = pw_plan(probs, nprob, M);
+  const PwPlan w = pw_plan(probs, nprob, M, max_workgroups);
   PwGroup g;
   RedGroup rg;
   memset(&g, 0, sizeof(g));
@@ -604,7 +607,7 @@ extern "C" size_t iq_wgrad_ws_bytes(int M, int N, int K) {
   iq_wgrad_problem_t b;
   memset(&b, 0, sizeof(b));
   b.N = N; b.K = K;
-  return iq_wgrad_grouped_ws_bytes(&b, 1, M);
+  return iq_wgrad_grouped_ws_bytes(&b, 1, M, 0);
 }
 
 extern "C" int iq_gemm_bf16_wgrad(const void* dY, int ldy, const void* X, int ldx, float* dW, float* dbias, int M,
@@ -612,5 +615,5 @@ extern "C" int iq_gemm_bf16_wgrad(const void* dY, int ldy, const void* X, int ld
   if (N <= 0 || K <= 0) return IQ_OK;
   iq_wgrad_problem_t b;
   b.dY = dY; b.ldy = ldy; b.X = X; b.ldx = ldx; b.dW = dW; b.dbias = dbias; b.N = N; b.K = K;
-  return iq_gemm_bf16_wgrad_grouped(&b, 1, M, ws, ws_bytes, accumulate, stream);
+  return iq_gemm_bf16_wgrad_grouped(&b, 1, M, ws, ws_bytes, accumulate, 0, stream);
 }

@@ -43,11 +43,21 @@ struct LayerOff {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Workgroup budget of a layer's grouped weight-gradient launch when it runs on the side stream next to the following
+// layer's dX chain (0 = no overlap: same stream, whole GPU).  IQ_BWD_OVERLAP=<workgroups> overrides.
+inline int bwd_overlap_budget() {
+  static const int v = getenv("IQ_BWD_OVERLAP") ? atoi(getenv("IQ_BWD_OVERLAP")) : 0;
+  return v < 0 ? 0 : v;
+}
+
 struct WsPlan {
   size_t step_ctr, patches, x0, head_feat, head_stat;
   struct L { size_t qkv, att, lse, z1, mean1, rstd1, x1, hid, z2, mean2, rstd2, x2; };
   std::vector<L> layers;
-  size_t gA, gB, gZ, gY, gZ1, gY1, gH, gQKV, gAtt, demb, wgrad_ws, wgrad_ws_bytes, ln_ws, embw_scratch;
+  size_t gA, gB, gAtt, demb, wgrad_ws, wgrad_ws_bytes, ln_ws, embw_scratch;
+  // dY operands of a layer's weight gradients: two sets (layer parity), so the gradients of layer l can still read
+  // theirs on the side stream while layer l-1's dX chain fills the other set
+  size_t gZ[2], gY[2], gZ1[2], gY1[2], gH[2], gQKV[2];
   size_t total;
 };
 
@@ -142,6 +152,9 @@ struct iq_model {
   const float* pe = nullptr;
   unsigned char* shadow = nullptr;
   std::string err;
+  // side stream + events for the overlapped weight gradients (created at bind)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
   uint64_t last_seed = 0;   // seed of the last training forward; backward regenerates the same masks
   bool last_tr = false;     // whether the last forward applied dropout
 
@@ -200,12 +213,14 @@ WsPlan plan_ws(const iq_model* m, int B) {
   }
   w.gA = take(M * D * 2);
   w.gB = take(M * D * 2);
-  w.gZ = take(M * D * 2);
-  w.gY = take(M * D * 2);
-  w.gZ1 = take(M * D * 2);
-  w.gY1 = take(M * D * 2);
-  w.gH = take(M * F * 2);
-  w.gQKV = take(M * 3 * D * 2);
+  for (int par = 0; par < 2; ++par) {
+    w.gZ[par] = take(M * D * 2);
+    w.gY[par] = take(M * D * 2);
+    w.gZ1[par] = take(M * D * 2);
+    w.gY1[par] = take(M * D * 2);
+    w.gH[par] = take(M * F * 2);
+    w.gQKV[par] = take(M * 3 * D * 2);
+  }
   w.gAtt = take(M * D * 2);
   w.demb = take(MT * D * 2);
   size_t wb = 0;
@@ -217,7 +232,8 @@ WsPlan plan_ws(const iq_model* m, int B) {
     g[1].N = (int)F; g[1].K = (int)D;
     g[2].N = (int)D; g[2].K = (int)D;
     g[3].N = (int)(3 * D); g[3].K = (int)D;
-    mx(iq_wgrad_grouped_ws_bytes(g, 4, (int)M));
+    mx(iq_wgrad_grouped_ws_bytes(g, 4, (int)M, 0));
+    mx(iq_wgrad_grouped_ws_bytes(g, 4, (int)M, bwd_overlap_budget()));
   }
   mx(iq_wgrad_ws_bytes((int)MT, (int)D, m->Ppad));
   w.wgrad_ws_bytes = wb;
@@ -355,6 +371,10 @@ extern "C" int iq_model_create(const iq_model_cfg_t* cfg, iq_model_t** out) {
 
 extern "C" void iq_model_destroy(iq_model_t* m) {
   if (!m) return;
+  if (m->side) {
+    (void)hipStreamDestroy(m->side);
+    for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(m->ev_ready[i]); (void)hipEventDestroy(m->ev_done[i]); }
+  }
   delete m;
 }
 extern "C" const char* iq_model_last_error(const iq_model_t* m) { return m ? m->err.c_str() : "null model"; }
@@ -383,6 +403,14 @@ extern "C" int iq_model_bind(iq_model_t* m, float* params, float* grads, const f
   if (!params || !pe || !shadow) return fail(m, IQ_ERR_ARG, "bind: params, pe and shadow are required");
   if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)shadow) & 255) return fail(m, IQ_ERR_ARG, "bind: buffers must be 256 B aligned");
   m->params = params; m->grads = grads; m->pe = pe; m->shadow = (unsigned char*)shadow;
+  if (!m->side && bwd_overlap_budget() > 0) {
+    bool ok = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2; ++i) {
+      ok = ok && hipEventCreateWithFlags(&m->ev_ready[i], hipEventDisableTiming) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&m->ev_done[i], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) return fail(m, IQ_ERR_LAUNCH, "bind: creating the side stream / events failed");
+  }
   if (m->table_uploaded_to != shadow && !m->ttab.empty()) {
     // one small synchronous copy per (re)binding of the shadow buffer; never on the step path
     if (hipMemcpy(m->shadow + m->sh_table, m->ttab.data(), m->ttab.size() * sizeof(TransDesc), hipMemcpyHostToDevice) != hipSuccess)
@@ -525,43 +553,63 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
     if (denc) f32_into_bf16_kernel<<<blocks_for((size_t)M * D / 8), 256, 0, st>>>(denc, (bf16*)(ws + w.gA), (size_t)M * D / 8, dlogits ? 1 : 0);
   }
   // The four weight gradients of a layer are independent of its dX chain and of each other, and their dY operands
-  // (gY|gZ, gH, gY1|gZ1, gQKV) all stay live until the next layer overwrites them: they run as ONE grouped launch
-  // (+ one slab reduce) at the end of the layer instead of four (+ four) in between -- one pipeline fill / drain,
-  // 3x fewer slab bytes.  (A side stream for them was measured twice: no gain, 7.00 vs 6.79 ms/step.)
+  // (gY|gZ, gH, gY1|gZ1, gQKV) all stay live until the chain of the layer two below overwrites them: they run as ONE
+  // grouped launch (+ one slab reduce) instead of four (+ four) -- one pipeline fill / drain, 3x fewer slab bytes.
+  // With a workgroup budget (bwd_overlap_budget) that launch goes to the side stream as soon as the layer's last dY
+  // exists and shares the CUs with the next layer's chain; every call joins the side stream before it returns.
+  const int budget = m->side ? bwd_overlap_budget() : 0;
+  bool pending[2] = {false, false};
   for (int sidx = (stage_hi > Lr ? Lr : stage_hi); sidx >= 1 && sidx >= stage_lo; --sidx) {
-    const int l = sidx - 1;
+    const int l = sidx - 1, par = l & 1;
     const LayerOff& o = m->L[l];
     const WsPlan::L& a = w.layers[l];
     const unsigned char* xin = l == 0 ? ws + w.x0 : ws + w.layers[l - 1].x2;
+    unsigned char *gZ = ws + w.gZ[par], *gY = ws + w.gY[par], *gZ1 = ws + w.gZ1[par], *gY1 = ws + w.gY1[par];
+    unsigned char *gH = ws + w.gH[par], *gQKV = ws + w.gQKV[par];
+    if (pending[par]) {                              // the gradients of layer l+2 still read this buffer set
+      (void)hipStreamWaitEvent(st, m->ev_done[par], 0);
+      pending[par] = false;
+    }
     iq_epilogue_t e;
     // norm2 backward (+ regenerated dropout2 mask)
     const iq_dropout_t dr2 = m->bwd_site(3 + 3 * l, step_dev, tr);
     IQ_TRY(iq_ln_bwd(ws + w.gA, ws + a.z2, (const float*)(ws + a.mean2), (const float*)(ws + a.rstd2), P + o.g2,
-                     ws + w.gZ, ws + w.gY, &dr2, G + o.g2, G + o.be2, lws, accumulate, M, D, stream), "norm2 bwd");
-    const unsigned char* dO2 = tr ? ws + w.gY : ws + w.gZ;
+                     gZ, gY, &dr2, G + o.g2, G + o.be2, lws, accumulate, M, D, stream), "norm2 bwd");
+    const unsigned char* dO2 = tr ? gY : gZ;
     memset(&e, 0, sizeof(e));
     e.gate = ws + a.hid; e.ldg = F; e.gate_scale = dscale;
-    IQ_TRY(iq_gemm_bf16_nt(dO2, D, m->sht(o.t_w2), D, ws + w.gH, F, M, F, D, &e, stream), "ffn2 dgrad");
+    IQ_TRY(iq_gemm_bf16_nt(dO2, D, m->sht(o.t_w2), D, gH, F, M, F, D, &e, stream), "ffn2 dgrad");
     memset(&e, 0, sizeof(e));
-    e.residual = ws + w.gZ; e.ldr = D;
-    IQ_TRY(iq_gemm_bf16_nt(ws + w.gH, F, m->sht(o.t_w1), F, ws + w.gB, D, M, D, F, &e, stream), "ffn1 dgrad");
+    e.residual = gZ; e.ldr = D;
+    IQ_TRY(iq_gemm_bf16_nt(gH, F, m->sht(o.t_w1), F, ws + w.gB, D, M, D, F, &e, stream), "ffn1 dgrad");
     // norm1 backward (+ dropout1 mask)
     const iq_dropout_t dr1 = m->bwd_site(1 + 3 * l, step_dev, tr);
     IQ_TRY(iq_ln_bwd(ws + w.gB, ws + a.z1, (const float*)(ws + a.mean1), (const float*)(ws + a.rstd1), P + o.g1,
-                     ws + w.gZ1, ws + w.gY1, &dr1, G + o.g1, G + o.be1, lws, accumulate, M, D, stream), "norm1 bwd");
-    const unsigned char* dAo = tr ? ws + w.gY1 : ws + w.gZ1;
+                     gZ1, gY1, &dr1, G + o.g1, G + o.be1, lws, accumulate, M, D, stream), "norm1 bwd");
+    const unsigned char* dAo = tr ? gY1 : gZ1;
     IQ_TRY(iq_gemm_bf16_nt(dAo, D, m->sht(o.t_wo), D, ws + w.gAtt, D, M, D, D, nullptr, stream), "out-proj dgrad");
-    IQ_TRY(iq_attn_bwd(ws + a.qkv, ws + a.att, ws + w.gAtt, (const float*)(ws + a.lse), ws + w.gQKV, B, S, H, m->dh, stream), "attention bwd");
-    memset(&e, 0, sizeof(e));
-    e.residual = ws + w.gZ1; e.ldr = D;
-    IQ_TRY(iq_gemm_bf16_nt(ws + w.gQKV, 3 * D, m->sht(o.t_wqkv), 3 * D, ws + w.gA, D, M, D, 3 * D, &e, stream), "qkv dgrad");
+    IQ_TRY(iq_attn_bwd(ws + a.qkv, ws + a.att, ws + w.gAtt, (const float*)(ws + a.lse), gQKV, B, S, H, m->dh, stream), "attention bwd");
     const iq_wgrad_problem_t wg[4] = {
-        {dO2, D, ws + a.hid, F, G + o.w2, G + o.b2, D, F},                 // ffn.linear2
-        {ws + w.gH, F, ws + a.x1, D, G + o.w1, G + o.b1, F, D},            // ffn.linear1
-        {dAo, D, ws + a.att, D, G + o.wo, G + o.bo, D, D},                 // attention.w_concat
-        {ws + w.gQKV, 3 * D, xin, D, G + o.wqkv, G + o.bqkv, 3 * D, D}};   // attention.w_q|w_k|w_v
-    IQ_TRY(iq_gemm_bf16_wgrad_grouped(wg, 4, M, wws, w.wgrad_ws_bytes, accumulate, stream), "layer weight gradients");
+        {dO2, D, ws + a.hid, F, G + o.w2, G + o.b2, D, F},            // ffn.linear2
+        {gH, F, ws + a.x1, D, G + o.w1, G + o.b1, F, D},              // ffn.linear1
+        {dAo, D, ws + a.att, D, G + o.wo, G + o.bo, D, D},            // attention.w_concat
+        {gQKV, 3 * D, xin, D, G + o.wqkv, G + o.bqkv, 3 * D, D}};     // attention.w_q|w_k|w_v
+    if (budget > 0) {
+      (void)hipEventRecord(m->ev_ready[par], st);
+      (void)hipStreamWaitEvent(m->side, m->ev_ready[par], 0);
+      IQ_TRY(iq_gemm_bf16_wgrad_grouped(wg, 4, M, wws, w.wgrad_ws_bytes, accumulate, budget, (iq_stream_t)m->side),
+             "layer weight gradients (side stream)");
+      (void)hipEventRecord(m->ev_done[par], m->side);
+      pending[par] = true;
+    }
+    memset(&e, 0, sizeof(e));
+    e.residual = gZ1; e.ldr = D;
+    IQ_TRY(iq_gemm_bf16_nt(gQKV, 3 * D, m->sht(o.t_wqkv), 3 * D, ws + w.gA, D, M, D, 3 * D, &e, stream), "qkv dgrad");
+    if (budget <= 0)
+      IQ_TRY(iq_gemm_bf16_wgrad_grouped(wg, 4, M, wws, w.wgrad_ws_bytes, accumulate, 0, stream), "layer weight gradients");
   }
+  for (int par = 0; par < 2; ++par)
+    if (pending[par]) (void)hipStreamWaitEvent(st, m->ev_done[par], 0);
   if (stage_lo == 0) {
     const iq_dropout_t dr0 = m->bwd_site(0, step_dev, tr);
     IQ_TRY(iq_embed_bwd_gather(ws + w.gA, ws + w.demb, m->has_cls ? G + m->cls : nullptr, B, S, m->tok, D, m->has_cls,
