@@ -48,6 +48,10 @@ size_t iq_ln_bwd_ws_bytes(int D);
 int iq_ln_bwd(const void* dx, const void* z, const float* mean, const float* rstd, const float* gamma, void* dz,
               void* dy, const iq_dropout_t* drop, float* dgamma, float* dbeta, float* ws, int accumulate, int M,
               int D, iq_stream_t stream);
+/* iq_ln_bwd with dgamma == dbeta == NULL leaves the per-block partial sums in ws as
+ * [iq_ln_bwd_partial_rows(M, D)][2*D] fp32 (dgamma partials | dbeta partials per row) for a later fused, fixed-order
+ * reduction: pass them as iq_reduce_seg_t entries to iq_gemm_bf16_wgrad_grouped. */
+int iq_ln_bwd_partial_rows(int M, int D);
 
 /* ---------------------------------------------------------------------------------------
  * bf16 MFMA GEMM, C[M,N] = epilogue(A[M,K] * B[N,K]^T), fp32 accumulate.
@@ -94,11 +98,22 @@ typedef struct iq_wgrad_problem {
   float* dbias;   /* fp32 [N] or NULL */
   int N, K;
 } iq_wgrad_problem_t;
+/* Extra fixed-order column reductions that ride on the group's slab-reduce launch (the LayerNorm gamma/beta partials
+ * of the same encoder layer): out[0..n) (+)= sum over `rows` rows of partials[row * row_stride + 0..n). */
+typedef struct iq_reduce_seg {
+  const float* partials;
+  int rows;
+  int64_t row_stride; /* floats */
+  float* out;
+  int64_t n;
+} iq_reduce_seg_t;
 /* max_workgroups: 0 = fill the GPU once (768 workgroups); a smaller budget leaves CU slots free for kernels of
- * another stream (the model's backward overlaps a layer's weight gradients with the next layer's dX chain). */
+ * another stream (the model's backward can overlap a layer's weight gradients with the next layer's dX chain).
+ * extra / nextra: up to 4 iq_reduce_seg_t (or NULL / 0). */
 size_t iq_wgrad_grouped_ws_bytes(const iq_wgrad_problem_t* probs, int nprob, int M, int max_workgroups);
 int iq_gemm_bf16_wgrad_grouped(const iq_wgrad_problem_t* probs, int nprob, int M, float* ws, size_t ws_bytes,
-                               int accumulate, int max_workgroups, iq_stream_t stream);
+                               int accumulate, int max_workgroups, const iq_reduce_seg_t* extra, int nextra,
+                               iq_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Scaled-dot-product attention core, softmax(Q K^T / sqrt(dh)) V per (frame, head), no mask,

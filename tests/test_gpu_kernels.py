@@ -283,15 +283,59 @@ def test_wgrad_grouped(L, M, shapes, budget):
         refs.append((dY.double().t() @ X.double(), dY.double().sum(0)))
     nbytes = L.iq_wgrad_grouped_ws_bytes(probs, len(shapes), M, budget)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev())
-    N.check(L.iq_gemm_bf16_wgrad_grouped(probs, len(shapes), M, ws.data_ptr(), nbytes, 0, budget, stream()), "grouped")
+    N.check(L.iq_gemm_bf16_wgrad_grouped(probs, len(shapes), M, ws.data_ptr(), nbytes, 0, budget, None, 0, stream()), "grouped")
     for (dY, X, dW, db), (rw, rb) in zip(keep, refs):
         close_f32(dW, rw, "dW")
         if db is not None:
             close_f32(db, rb, "db")
-    N.check(L.iq_gemm_bf16_wgrad_grouped(probs, len(shapes), M, ws.data_ptr(), nbytes, 1, budget, stream()), "grouped acc")
+    N.check(L.iq_gemm_bf16_wgrad_grouped(probs, len(shapes), M, ws.data_ptr(), nbytes, 1, budget, None, 0, stream()), "grouped acc")
     for (dY, X, dW, db), (rw, rb) in zip(keep, refs):
         close_f32(dW, 2 * rw, "dW acc")
-    assert L.iq_gemm_bf16_wgrad_grouped(probs, len(shapes), M, ws.data_ptr(), nbytes - 1, 0, budget, stream()) != 0   # ws too small
+    assert L.iq_gemm_bf16_wgrad_grouped(probs, len(shapes), M, ws.data_ptr(), nbytes - 1, 0, budget, None, 0, stream()) != 0   # ws too small
+
+
+@pytest.mark.parametrize("M,D,with_gemm", [(3940, 192, True), (1000, 128, False), (50432, 192, True)])
+def test_ln_bwd_partials_reduced_with_the_group(L, M, D, with_gemm):
+    """iq_ln_bwd(dgamma=dbeta=NULL) + iq_reduce_seg_t on the grouped launch == iq_ln_bwd reducing on its own (bitwise)."""
+    N = _N()
+    g = torch.Generator(device="cuda").manual_seed(M + D)
+    z = bf(torch.randn(M, D, device=dev(), generator=g)); dx = bf(torch.randn(M, D, device=dev(), generator=g))
+    gamma = torch.randn(D, device=dev(), generator=g)
+    x = torch.empty_like(z); mean = torch.empty(M, device=dev()); rstd = torch.empty(M, device=dev())
+    N.check(L.iq_ln_fwd(z.data_ptr(), gamma.data_ptr(), gamma.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), M, D,
+                        1e-12, stream()), "ln_fwd")
+    ws = torch.empty(L.iq_ln_bwd_ws_bytes(D), dtype=torch.uint8, device=dev())
+    dz = torch.empty_like(z)
+    dg_ref, db_ref = torch.empty(D, device=dev()), torch.empty(D, device=dev())
+    N.check(L.iq_ln_bwd(dx.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dz.data_ptr(), None,
+                        None, dg_ref.data_ptr(), db_ref.data_ptr(), ws.data_ptr(), 0, M, D, stream()), "ln_bwd")
+    dz_ref = dz.clone(); dz.zero_()
+    N.check(L.iq_ln_bwd(dx.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dz.data_ptr(), None,
+                        None, None, None, ws.data_ptr(), 0, M, D, stream()), "ln_bwd partial")
+    assert torch.equal(dz, dz_ref)
+    rows = L.iq_ln_bwd_partial_rows(M, D)
+    assert 0 < rows <= 512
+    part = ws.view(torch.float32)[: rows * 2 * D].view(rows, 2 * D)
+    dg, db = torch.full((D,), 7.0, device=dev()), torch.full((D,), 7.0, device=dev())
+    segs = (N.ReduceSeg * 2)()
+    for i, (off, out) in enumerate([(0, dg), (D, db)]):
+        segs[i].partials = ws.data_ptr() + 4 * off; segs[i].rows = rows; segs[i].row_stride = 2 * D
+        segs[i].out = out.data_ptr(); segs[i].n = D
+    if with_gemm:
+        dY = bf(torch.randn(M, 64, device=dev(), generator=g)); X = bf(torch.randn(M, 64, device=dev(), generator=g))
+        dW = torch.empty(64, 64, device=dev())
+        pr = (N.WgradProblem * 1)()
+        pr[0].dY = dY.data_ptr(); pr[0].ldy = 64; pr[0].X = X.data_ptr(); pr[0].ldx = 64; pr[0].dW = dW.data_ptr()
+        pr[0].dbias = None; pr[0].N = 64; pr[0].K = 64
+        nb = L.iq_wgrad_grouped_ws_bytes(pr, 1, M, 0); wws = torch.empty(nb, dtype=torch.uint8, device=dev())
+        N.check(L.iq_gemm_bf16_wgrad_grouped(pr, 1, M, wws.data_ptr(), nb, 0, 0, segs, 2, stream()), "grouped + extra")
+        close_f32(dW, dY.double().t() @ X.double(), "dW")
+    else:
+        N.check(L.iq_gemm_bf16_wgrad_grouped(None, 0, M, None, 0, 0, 0, segs, 2, stream()), "extra only")
+    # same partial rows, fixed-order sums: agree with the stand-alone reduce to rounding (different association)
+    close_f32(dg, dg_ref, "dgamma", 1e-5)
+    close_f32(db, db_ref, "dbeta", 1e-5)
+    close_f32(dg, part[:, :D].double().sum(0), "dgamma vs partial rows", 1e-6)
 
 
 def test_wgrad_exact_integers(L):

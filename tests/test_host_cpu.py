@@ -53,6 +53,7 @@ def test_struct_layouts_match_the_header_field_order():
     assert fields("iq_epilogue") == [f[0] for f in N.Epilogue._fields_]
     assert fields("iq_model_cfg") == [f[0] for f in N.ModelCfg._fields_]
     assert fields("iq_wgrad_problem") == [f[0] for f in N.WgradProblem._fields_]
+    assert fields("iq_reduce_seg") == [f[0] for f in N.ReduceSeg._fields_]
 
 
 def test_host_only_queries_work_without_a_gpu():

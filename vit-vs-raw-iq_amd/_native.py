@@ -34,6 +34,11 @@ class WgradProblem(C.Structure):
                 ("dbias", C.c_void_p), ("N", C.c_int), ("K", C.c_int)]
 
 
+class ReduceSeg(C.Structure):
+    _fields_ = [("partials", C.c_void_p), ("rows", C.c_int), ("row_stride", C.c_int64), ("out", C.c_void_p),
+                ("n", C.c_int64)]
+
+
 class ModelCfg(C.Structure):
     _fields_ = [("kind", C.c_int), ("in_channels", C.c_int), ("img_h", C.c_int), ("img_w", C.c_int),
                 ("patch", C.c_int), ("seq_length", C.c_int), ("conv_k", C.c_int), ("use_cls", C.c_int),
@@ -49,12 +54,13 @@ SIGNATURES = {
     "iq_ln_supported": (_I, [_I]),
     "iq_ln_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "iq_ln_bwd_ws_bytes": (_Z, [_I]),
+    "iq_ln_bwd_partial_rows": (_I, [_I, _I]),
     "iq_ln_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(Dropout), _P, _P, _P, _I, _I, _I, _P]),
     "iq_gemm_bf16_nt": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, C.POINTER(Epilogue), _P]),
     "iq_wgrad_ws_bytes": (_Z, [_I, _I, _I]),
     "iq_gemm_bf16_wgrad": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _Z, _I, _P]),
     "iq_wgrad_grouped_ws_bytes": (_Z, [_P, _I, _I, _I]),
-    "iq_gemm_bf16_wgrad_grouped": (_I, [_P, _I, _I, _P, _Z, _I, _I, _P]),
+    "iq_gemm_bf16_wgrad_grouped": (_I, [_P, _I, _I, _P, _Z, _I, _I, _P, _I, _P]),
     "iq_attn_supported": (_I, [_I, _I]),
     "iq_attn_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "iq_attn_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

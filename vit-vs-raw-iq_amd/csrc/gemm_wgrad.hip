@@ -379,34 +379,41 @@ __global__ __launch_bounds__(PW_THREADS, 3) void wgrad_pw_kernel(const PwGroup g
 // out[i] (+)= sum_s slab[s][i] for up to 2*PW_MAXP segments (weights and biases of a group) in ONE launch.
 // Block = 64 float4 columns x 4 split slices (coalesced 1 KiB rows, 4x the loads in flight of a one-thread-per-column
 // loop), slices combined through LDS in fixed order: bit-reproducible.
-struct RedSeg { const float* slab; float* out; long n; int blk0; };
-struct RedGroup { RedSeg s[2 * PW_MAXP]; int nseg, splits, accumulate; };
+constexpr int RED_MAXX = 4;   // extra (LayerNorm partial) segments
+struct RedSeg { const float* slab; float* out; long n, stride; int rows, blk0, tall; };
+struct RedGroup { RedSeg s[2 * PW_MAXP + RED_MAXX]; int nseg, accumulate; };
+
+// Block shape per segment: "wide" = 64 float4 columns x 4 row slices (few slab rows, many columns), "tall" = 16 columns
+// x 16 slices (hundreds of LayerNorm partial rows, 192 columns): keeps every thread's serial chain short either way.
+inline int red_blocks(long n, int tall) { return (int)((n + (tall ? 63 : 255)) / (tall ? 64 : 256)); }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedGroup g) {
-  __shared__ f32x4 part[4][64];
+  __shared__ f32x4 part[256];
   RedSeg sg = g.s[0];
 #pragma unroll
-  for (int i = 1; i < 2 * PW_MAXP; ++i)
+  for (int i = 1; i < 2 * PW_MAXP + RED_MAXX; ++i)
     if (i < g.nseg && (int)blockIdx.x >= g.s[i].blk0) sg = g.s[i];
   const float* __restrict__ slab = sg.slab;
   float* __restrict__ out = sg.out;
-  const long n = sg.n;
+  const long n = sg.n, stride = sg.stride;
   const long blk = (long)blockIdx.x - sg.blk0;
-  const int splits = g.splits, accumulate = g.accumulate;
-  const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const long i = (blk * 64 + col) * 4;
+  const int rows = sg.rows, accumulate = g.accumulate;
+  const int ncol = sg.tall ? 16 : 64, nsl = 256 / ncol;
+  const int col = threadIdx.x % ncol, sl = threadIdx.x / ncol;
+  const long i = (blk * ncol + col) * 4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (i + 4 <= n) {
-#pragma unroll 4
-    for (int sp = sl; sp < splits; sp += 4) s += *reinterpret_cast<const f32x4*>(slab + (long)sp * n + i);
+#pragma unroll 8
+    for (int sp = sl; sp < rows; sp += nsl) s += *reinterpret_cast<const f32x4*>(slab + (long)sp * stride + i);
   } else if (i < n) {
-    for (int sp = sl; sp < splits; sp += 4)
-      for (int e = 0; e < 4 && i + e < n; ++e) s[e] += slab[(long)sp * n + i + e];
+    for (int sp = sl; sp < rows; sp += nsl)
+      for (int e = 0; e < 4 && i + e < n; ++e) s[e] += slab[(long)sp * stride + i + e];
   }
-  part[sl][col] = s;
+  part[sl * ncol + col] = s;
   __syncthreads();
   if (sl == 0 && i < n) {
-    f32x4 t = part[0][col] + part[1][col] + part[2][col] + part[3][col];
+    f32x4 t = part[col];
+    for (int k = 1; k < nsl; ++k) t += part[k * ncol + col];
     if (i + 4 <= n) {
       f32x4* o = reinterpret_cast<f32x4*>(out + i);
       *o = accumulate ? *o + t : t;
@@ -514,11 +521,11 @@ int wgrad_shared_one(const iq_wgrad_problem_t& pb, int M, float* ws, int accumul
   RedGroup rg;
   memset(&rg, 0, sizeof(rg));
   const long n = (long)N * K;
-  rg.s[0] = RedSeg{q.slab, pb.dW, n, 0};
+  rg.s[0] = RedSeg{q.slab, pb.dW, n, n, w.splits, 0, 0};
   int nblk = (int)((n + 255) / 256);
   rg.nseg = 1;
-  if (pb.dbias) { rg.s[1] = RedSeg{q.bslab, pb.dbias, (long)N, nblk}; nblk += (N + 255) / 256; rg.nseg = 2; }
-  rg.splits = w.splits; rg.accumulate = accumulate;
+  if (pb.dbias) { rg.s[1] = RedSeg{q.bslab, pb.dbias, (long)N, (long)N, w.splits, nblk, 0}; nblk += (N + 255) / 256; rg.nseg = 2; }
+  rg.accumulate = accumulate;
   return launch_reduce(rg, nblk, st);
 }
 
@@ -541,9 +548,22 @@ extern "C" size_t iq_wgrad_grouped_ws_bytes(const iq_wgrad_problem_t* probs, int
 }
 
 extern "C" int iq_gemm_bf16_wgrad_grouped(const iq_wgrad_problem_t* probs, int nprob, int M, float* ws, size_t ws_bytes,
-                                          int accumulate, int max_workgroups, iq_stream_t stream) {
-  if (nprob <= 0) return IQ_OK;
-  if (!probs || !ws || M <= 0) return IQ_ERR_ARG;
+                                          int accumulate, int max_workgroups, const iq_reduce_seg_t* extra, int nextra,
+                                          iq_stream_t stream) {
+  if (nextra < 0 || nextra > RED_MAXX || (nextra > 0 && !extra)) return IQ_ERR_ARG;
+  for (int i = 0; i < nextra; ++i)
+    if (!extra[i].partials || !extra[i].out || extra[i].rows <= 0 || extra[i].n <= 0 || extra[i].row_stride < extra[i].n ||
+        (extra[i].row_stride % 4) || (((uintptr_t)extra[i].partials | (uintptr_t)extra[i].out) & 15))
+      return IQ_ERR_ARG;
+  auto add_extra = [&](RedGroup& rg, int& nblk) {
+    for (int i = 0; i < nextra; ++i) {
+      const int tall = extra[i].rows >= 64;
+      rg.s[rg.nseg++] = RedSeg{extra[i].partials, extra[i].out, (long)extra[i].n, (long)extra[i].row_stride, extra[i].rows, nblk, tall};
+      nblk += red_blocks(extra[i].n, tall);
+    }
+  };
+  if (nprob <= 0 && nextra == 0) return IQ_OK;
+  if (nprob > 0 && (!probs || !ws || M <= 0)) return IQ_ERR_ARG;
   for (int i = 0; i < nprob; ++i) {
     const iq_wgrad_problem_t& b = probs[i];
     if (b.N <= 0 || b.K <= 0 || !b.dY || !b.X || !b.dW) return IQ_ERR_ARG;
@@ -557,11 +577,19 @@ extern "C" int iq_gemm_bf16_wgrad_grouped(const iq_wgrad_problem_t* probs, int n
     for (int i = 0; i < nprob; ++i) {
       int rc;
       if (pw_eligible(probs[i].N, probs[i].K)) {
-        rc = iq_gemm_bf16_wgrad_grouped(probs + i, 1, M, ws, ws_bytes, accumulate, max_workgroups, stream);
+        rc = iq_gemm_bf16_wgrad_grouped(probs + i, 1, M, ws, ws_bytes, accumulate, max_workgroups, nullptr, 0, stream);
       } else {
         rc = wgrad_shared_one(probs[i], M, ws, accumulate, st);
       }
       if (rc != IQ_OK) return rc;
+    }
+    if (nextra > 0) {
+      RedGroup rg;
+      memset(&rg, 0, sizeof(rg));
+      int nblk = 0;
+      add_extra(rg, nblk);
+      rg.accumulate = accumulate;
+      launch_reduce(rg, nblk, st);
     }
     return iq_launch_status();
   }
@@ -586,15 +614,16 @@ extern "C" int iq_gemm_bf16_wgrad_grouped(const iq_wgrad_problem_t* probs, int n
     tile0 += q.tiles_n * q.tiles_k;
     const long n = (long)b.N * b.K;
     q.slab = cur; cur += (size_t)w.splits * pad4((size_t)n);
-    rg.s[rg.nseg++] = RedSeg{q.slab, b.dW, n, nblk};
+    rg.s[rg.nseg++] = RedSeg{q.slab, b.dW, n, n, w.splits, nblk, 0};
     nblk += (int)((n + 255) / 256);
     if (b.dbias) {
       q.bslab = cur; cur += (size_t)w.splits * pad4(b.N);
-      rg.s[rg.nseg++] = RedSeg{q.bslab, b.dbias, (long)b.N, nblk};
+      rg.s[rg.nseg++] = RedSeg{q.bslab, b.dbias, (long)b.N, (long)b.N, w.splits, nblk, 0};
       nblk += (b.N + 255) / 256;
     }
   }
-  rg.splits = w.splits; rg.accumulate = accumulate;
+  add_extra(rg, nblk);
+  rg.accumulate = accumulate;
   const size_t lds_pw = (size_t)4 * PW_WAVE_LDS * 2;   // 40 KiB >= 4 x 32 x PW_RED_LD x 4 B of the final sum
   static_assert(4 * PW_WAVE_LDS * 2 >= 4 * 32 * PW_RED_LD * 4, "reduction area must fit the stage areas");
   wgrad_pw_kernel<<<w.ntile * w.splits, PW_THREADS, lds_pw, st>>>(g);
@@ -615,5 +644,5 @@ extern "C" int iq_gemm_bf16_wgrad(const void* dY, int ldy, const void* X, int ld
   if (N <= 0 || K <= 0) return IQ_OK;
   iq_wgrad_problem_t b;
   b.dY = dY; b.ldy = ldy; b.X = X; b.ldx = ldx; b.dW = dW; b.dbias = dbias; b.N = N; b.K = K;
-  return iq_gemm_bf16_wgrad_grouped(&b, 1, M, ws, ws_bytes, accumulate, 0, stream);
+  return iq_gemm_bf16_wgrad_grouped(&b, 1, M, ws, ws_bytes, accumulate, 0, nullptr, 0, stream);
 }

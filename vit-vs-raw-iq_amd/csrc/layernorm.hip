@@ -267,12 +267,26 @@ extern "C" int iq_ln_fwd(const void* z, const float* gamma, const float* beta, v
 
 extern "C" size_t iq_ln_bwd_ws_bytes(int D) { return (size_t)LN_MAX_BLOCKS * 2 * D * sizeof(float); }
 
+extern "C" int iq_ln_bwd_partial_rows(int M, int D) {
+  LnShape s;
+  if (M <= 0 || !ln_shape(D, &s)) return 0;
+  int rows = 0;
+  bool ok = ln_dispatch(s, [&](auto lpr, auto nv) {
+    constexpr int LPR = decltype(lpr)::value;
+    rows = ln_grid(M, (64 / LPR) * 4);
+  });
+  if (!ok) rows = ln_grid(M, 4);
+  return rows;
+}
+
 extern "C" int iq_ln_bwd(const void* dx, const void* z, const float* mean, const float* rstd, const float* gamma,
                          void* dz, void* dy, const iq_dropout_t* drop, float* dgamma, float* dbeta, float* ws,
                          int accumulate, int M, int D, iq_stream_t stream) {
   LnShape s;
   if (M <= 0) return IQ_OK;
-  if (!dx || !z || !mean || !rstd || !gamma || !dz || !dgamma || !dbeta || !ws) return IQ_ERR_ARG;
+  if (!dx || !z || !mean || !rstd || !gamma || !dz || !ws) return IQ_ERR_ARG;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return IQ_ERR_ARG;
+  const bool reduce_now = dgamma != nullptr;   // else: partial rows stay in ws for a fused reduction (iq_reduce_seg_t)
   if (!ln_shape(D, &s)) return IQ_ERR_UNSUPPORTED;
   const bool dropping = drop && drop->p > 0.f;
   if (dropping && !dy) return IQ_ERR_ARG;
@@ -304,7 +318,7 @@ extern "C" int iq_ln_bwd(const void* dx, const void* z, const float* mean, const
       k<<<nblk, LN_THREADS, lds, st>>>((const bf16*)dx, (const bf16*)z, mean, rstd, gamma, (bf16*)dz, (bf16*)dy, rng,
                                        thresh, dscale, ws, M, D);
     }
-    ln_bwd_reduce_kernel<<<(2 * D + 31) / 32, 1024, 0, st>>>(ws, nblk, D, dgamma, dbeta, accumulate);
+    if (reduce_now) ln_bwd_reduce_kernel<<<(2 * D + 31) / 32, 1024, 0, st>>>(ws, nblk, D, dgamma, dbeta, accumulate);
   });
   if (!ok) ok = ln_dispatch_masked(D, [&](auto nv) {
     constexpr int NV = decltype(nv)::value;
@@ -317,7 +331,7 @@ extern "C" int iq_ln_bwd(const void* dx, const void* z, const float* mean, const
     else
       ln_bwd_kernel<64, NV, false, true><<<nblk, LN_THREADS, lds, st>>>((const bf16*)dx, (const bf16*)z, mean, rstd, gamma,
                                                                        (bf16*)dz, (bf16*)dy, rng, thresh, dscale, ws, M, D);
-    ln_bwd_reduce_kernel<<<(2 * D + 31) / 32, 1024, 0, st>>>(ws, nblk, D, dgamma, dbeta, accumulate);
+    if (reduce_now) ln_bwd_reduce_kernel<<<(2 * D + 31) / 32, 1024, 0, st>>>(ws, nblk, D, dgamma, dbeta, accumulate);
   });
   if (!ok) return IQ_ERR_UNSUPPORTED;
   return rc != IQ_OK ? rc : iq_launch_status();

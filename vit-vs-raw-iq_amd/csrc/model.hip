@@ -54,7 +54,7 @@ struct WsPlan {
   size_t step_ctr, patches, x0, head_feat, head_stat;
   struct L { size_t qkv, att, lse, z1, mean1, rstd1, x1, hid, z2, mean2, rstd2, x2; };
   std::vector<L> layers;
-  size_t gA, gB, gAtt, demb, wgrad_ws, wgrad_ws_bytes, ln_ws, embw_scratch;
+  size_t gA, gB, gAtt, demb, wgrad_ws, wgrad_ws_bytes, ln_part[2][2], embw_scratch;
   // dY operands of a layer's weight gradients: two sets (layer parity), so the gradients of layer l can still read
   // theirs on the side stream while layer l-1's dX chain fills the other set
   size_t gZ[2], gY[2], gZ1[2], gY1[2], gH[2], gQKV[2];
@@ -238,7 +238,8 @@ WsPlan plan_ws(const iq_model* m, int B) {
   mx(iq_wgrad_ws_bytes((int)MT, (int)D, m->Ppad));
   w.wgrad_ws_bytes = wb;
   w.wgrad_ws = take(wb);
-  w.ln_ws = take(iq_ln_bwd_ws_bytes((int)D));
+  for (int par = 0; par < 2; ++par)           // per layer parity: norm2 / norm1 partial rows, reduced with the layer's slabs
+    for (int k = 0; k < 2; ++k) w.ln_part[par][k] = take(iq_ln_bwd_ws_bytes((int)D));
   w.embw_scratch = take((size_t)D * m->Ppad * 4 + 256);
   w.total = cur;
   return w;
@@ -537,7 +538,6 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
   const float* P = m->params;
   float* G = m->grads;
   float* wws = (float*)(ws + w.wgrad_ws);
-  float* lws = (float*)(ws + w.ln_ws);
   const float dscale = tr ? dropout_scale(c.drop_prob) : 1.f;
 
   if (stage_hi == Lr + 1) {
@@ -573,8 +573,10 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
     iq_epilogue_t e;
     // norm2 backward (+ regenerated dropout2 mask)
     const iq_dropout_t dr2 = m->bwd_site(3 + 3 * l, step_dev, tr);
+    float* lp2 = (float*)(ws + w.ln_part[par][0]);
+    float* lp1 = (float*)(ws + w.ln_part[par][1]);
     IQ_TRY(iq_ln_bwd(ws + w.gA, ws + a.z2, (const float*)(ws + a.mean2), (const float*)(ws + a.rstd2), P + o.g2,
-                     gZ, gY, &dr2, G + o.g2, G + o.be2, lws, accumulate, M, D, stream), "norm2 bwd");
+                     gZ, gY, &dr2, nullptr, nullptr, lp2, accumulate, M, D, stream), "norm2 bwd");
     const unsigned char* dO2 = tr ? gY : gZ;
     memset(&e, 0, sizeof(e));
     e.gate = ws + a.hid; e.ldg = F; e.gate_scale = dscale;
@@ -585,7 +587,7 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
     // norm1 backward (+ dropout1 mask)
     const iq_dropout_t dr1 = m->bwd_site(1 + 3 * l, step_dev, tr);
     IQ_TRY(iq_ln_bwd(ws + w.gB, ws + a.z1, (const float*)(ws + a.mean1), (const float*)(ws + a.rstd1), P + o.g1,
-                     gZ1, gY1, &dr1, G + o.g1, G + o.be1, lws, accumulate, M, D, stream), "norm1 bwd");
+                     gZ1, gY1, &dr1, nullptr, nullptr, lp1, accumulate, M, D, stream), "norm1 bwd");
     const unsigned char* dAo = tr ? gY1 : gZ1;
     IQ_TRY(iq_gemm_bf16_nt(dAo, D, m->sht(o.t_wo), D, ws + w.gAtt, D, M, D, D, nullptr, stream), "out-proj dgrad");
     IQ_TRY(iq_attn_bwd(ws + a.qkv, ws + a.att, ws + w.gAtt, (const float*)(ws + a.lse), gQKV, B, S, H, m->dh, stream), "attention bwd");
@@ -594,10 +596,14 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
         {gH, F, ws + a.x1, D, G + o.w1, G + o.b1, F, D},              // ffn.linear1
         {dAo, D, ws + a.att, D, G + o.wo, G + o.bo, D, D},            // attention.w_concat
         {gQKV, 3 * D, xin, D, G + o.wqkv, G + o.bqkv, 3 * D, D}};     // attention.w_q|w_k|w_v
+    // the LayerNorm gamma/beta partial rows of this layer ride on the same reduce launch
+    const int lrows = iq_ln_bwd_partial_rows(M, D);
+    const iq_reduce_seg_t lnseg[4] = {{lp2, lrows, 2L * D, G + o.g2, D}, {lp2 + D, lrows, 2L * D, G + o.be2, D},
+                                      {lp1, lrows, 2L * D, G + o.g1, D}, {lp1 + D, lrows, 2L * D, G + o.be1, D}};
     if (budget > 0) {
       (void)hipEventRecord(m->ev_ready[par], st);
       (void)hipStreamWaitEvent(m->side, m->ev_ready[par], 0);
-      IQ_TRY(iq_gemm_bf16_wgrad_grouped(wg, 4, M, wws, w.wgrad_ws_bytes, accumulate, budget, (iq_stream_t)m->side),
+      IQ_TRY(iq_gemm_bf16_wgrad_grouped(wg, 4, M, wws, w.wgrad_ws_bytes, accumulate, budget, lnseg, 4, (iq_stream_t)m->side),
              "layer weight gradients (side stream)");
       (void)hipEventRecord(m->ev_done[par], m->side);
       pending[par] = true;
@@ -606,7 +612,7 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
     e.residual = gZ1; e.ldr = D;
     IQ_TRY(iq_gemm_bf16_nt(gQKV, 3 * D, m->sht(o.t_wqkv), 3 * D, ws + w.gA, D, M, D, 3 * D, &e, stream), "qkv dgrad");
     if (budget <= 0)
-      IQ_TRY(iq_gemm_bf16_wgrad_grouped(wg, 4, M, wws, w.wgrad_ws_bytes, accumulate, 0, stream), "layer weight gradients");
+      IQ_TRY(iq_gemm_bf16_wgrad_grouped(wg, 4, M, wws, w.wgrad_ws_bytes, accumulate, 0, lnseg, 4, stream), "layer weight gradients");
   }
   for (int par = 0; par < 2; ++par)
     if (pending[par]) (void)hipStreamWaitEvent(st, m->ev_done[par], 0);
