@@ -147,6 +147,38 @@ def test_gemm_plain_and_bias_relu(L, M, N_, K):
     close_bf16(run_gemm(L, A, B, M, N_, K, bias=bias, relu=1), torch.relu(ref + bias.double()), "bias+relu")
 
 
+@pytest.mark.parametrize("M,N_,K", [(16384, 576, 192), (16384 + 77, 768, 192), (20000, 512, 128), (50432, 768, 192)])
+def test_gemm_wave_private_wide_n(L, M, N_, K):
+    """Wide N, K <= 192, many rows -- the cfg B FFN1 / QKV / FFN2-dgrad shapes, also what the opt-in wave-private kernel
+    (gemm_wp.hip, IQ_GEMM_WP=1) serves: ragged M tail, strided A, bias+ReLU, gate, residual, and a dropout mask that
+    depends only on (seed, step, site, element index), not on M or on which kernel ran."""
+    import os
+    g = torch.Generator(device="cuda").manual_seed(M + N_)
+    Abig = bf(torch.randn(M, K + 8, device=dev(), generator=g))
+    A = Abig[:, :K]
+    B = bf(torch.randn(N_, K, device=dev(), generator=g) / math.sqrt(K))
+    bias = torch.randn(N_, device=dev(), generator=g)
+    ref = A.double() @ B.double().t()
+    close_bf16(run_gemm(L, A, B, M, N_, K), ref, "plain")
+    close_bf16(run_gemm(L, A, B, M, N_, K, bias=bias, relu=1), torch.relu(ref + bias.double()), "bias+relu")
+    G = bf(torch.randn(M, N_, device=dev(), generator=g)); R = bf(torch.randn(M, N_, device=dev(), generator=g))
+    out = run_gemm(L, A, B, M, N_, K, gate=G, ldg=N_, gate_scale=1.25)
+    close_bf16(out, torch.where(G.double() > 0, ref * 1.25, torch.zeros_like(ref)), "gate")
+    close_bf16(run_gemm(L, A, B, M, N_, K, residual=R, ldr=N_), ref + R.double(), "residual")
+    dr = _drop(99, 3, 5, 0.25)
+    out = run_gemm(L, A, B, M, N_, K, bias=bias, relu=1, drop=dr)
+    keep = out.float() != 0
+    full = torch.relu(ref + bias.double())
+    frac = keep.float().mean().item() / (full != 0).float().mean().item()
+    assert abs(frac - 0.75) < 0.01, frac
+    close_bf16(out.float()[keep], (full / 0.75).float()[keep], "dropout scale")
+    # the mask depends only on (seed, step, site, element index): a small-M call (tiled kernel) must reproduce its rows
+    Ms = 1000
+    out_s = run_gemm(L, A[:Ms], B, Ms, N_, K, bias=bias, relu=1, drop=dr)
+    sel = full[:Ms].abs() > 0.05                       # away from the ReLU edge, where summation order could flip a sign
+    assert torch.equal((out_s.float() != 0)[sel], keep[:Ms][sel])
+
+
 def test_gemm_asymmetric_layout(L):
     """A = I picks out B^T exactly: catches swapped fragment / C-layout maps (guide 3)."""
     K = 64

@@ -122,6 +122,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
           for (int e = 0; e < 8; ++e) w[e] += (float)res[i][jp][e];
         }
+#ifdef IQ_EPI_NO_STORE
+        if (p.ldc < 0)
+#endif
         *reinterpret_cast<bf16x8*>(p.C + orow[i] * p.ldc + col) = pack8(w);
       }
     }

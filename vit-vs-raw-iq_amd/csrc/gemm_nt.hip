@@ -245,6 +245,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
 }  // namespace
 
 int iq_gemm_ws_try_launch(const GemmParams& p, int epi_mode, hipStream_t st);   // gemm_ws.hip
+int iq_gemm_wp_try_launch(const GemmParams& p, int epi_mode, hipStream_t st);   // gemm_wp.hip
 
 #ifdef IQ_GEMM_STAMPS
 static unsigned long long* g_stamps = nullptr;
@@ -300,6 +301,10 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   p.stagger = stagger;
   // The weight-stationary persistent kernel (gemm_ws.hip) is correct but measured 5-25 % SLOWER than the tiled
   // kernels on the ViT-Tiny shapes (one 8-wave workgroup per CU serialises its own phases): opt-in only.
+  // Wide-N, K <= 192: wave-private kernel with the weight block in registers (gemm_wp.hip); measured equal to the
+  // tiled kernel (see its header), so opt-in: IQ_GEMM_WP=1.
+  static const bool use_wp = getenv("IQ_GEMM_WP") != nullptr;
+  if (use_wp && !force_reg && iq_gemm_wp_try_launch(p, epi_mode, st) == IQ_OK) return iq_launch_status();
   static const bool use_ws = getenv("IQ_GEMM_WS") != nullptr;
   if (use_ws && !force_reg && iq_gemm_ws_try_launch(p, epi_mode, st) == IQ_OK) return iq_launch_status();
   const size_t lds_async = (size_t)3 * (bm + bn) * 32 * 2;     // ring of 3 stages
