@@ -38,6 +38,13 @@ constexpr int EPI_RES = 1, EPI_GATE = 2, EPI_PE = 4;
 template <int MT, int NT, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][NT], int row0, int col0, int lane) {
   static_assert(NT % 2 == 0, "column tiles are consumed in pairs");
+#ifdef IQ_EPI_SKIP   // ablation build: timing only
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) asm volatile("" :: "v"(acc[i][j]));
+  return;
+#endif
   constexpr int NP = NT / 2;       // column-tile pairs
   const int g = lane >> 4, c16 = lane & 15;
   const bool odd = (g & 1) != 0;

@@ -228,11 +228,18 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
       const int row = wn * WN + j * 16 + (lane & 15);
       bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + row * BK2 + (ch ^ swz64(row)) * 8);
     }
+#ifdef IQ_NT_NO_MFMA   // ablation build (scripts/dbg/ablate.py): timing only
+#pragma unroll
+    for (int i = 0; i < MT; ++i) asm volatile("" :: "v"(af[i]));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) asm volatile("" :: "v"(bfr[j]));
+#else
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile: see gemm_epilogue
+#endif
   }
   IQ_STAMP(2);
   IQ_STAMP(3);
