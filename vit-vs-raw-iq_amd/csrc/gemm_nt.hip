@@ -204,9 +204,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
   if (nk > 1) issue(1);
   for (int ks = 0; ks < nk; ++ks) {
     if (ks + 1 < nk) {
-      if (PER_STAGE == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else if (PER_STAGE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER_STAGE) : "memory");   // all but the youngest stage have landed
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
