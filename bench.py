@@ -235,6 +235,18 @@ def main():
             ach = w["bytes"] / (dur_ms * 1e-3) / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+        # HBM bytes per launch from the PMC counters cannot be collected inside this process (rocprofv3 --pmc passes,
+        # scripts/pmc_family.sh); report the committed measurement of the same workload when there is one.
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_pmc_family_cfg{a.config}.json")
+        if os.path.exists(pmc_path) and a.batch in (0, CONFIGS[a.config][2]) and a.drop < 0 and world == 1:
+            try:
+                with open(pmc_path) as fh:
+                    pmc = json.load(fh)
+                if dom in pmc:
+                    roof["traffic"] = int(pmc[dom]["hbm_bytes_per_launch"])
+                    roof["traffic_source"] = os.path.relpath(pmc_path, os.path.dirname(os.path.abspath(__file__)))
+            except (OSError, ValueError, KeyError):
+                pass
         roof["avg_launch_us"] = round(dur_ms * 1e3 / launches, 2)
         roof["launches_per_step"] = launches
         roof["algorithmic_bytes_per_launch"] = int(w["bytes"] / launches)
