@@ -80,6 +80,16 @@ typedef struct iq_epilogue {
 int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                     const iq_epilogue_t* epi, iq_stream_t stream);
 
+/* Two chained NT GEMMs in one launch: H[M,F] = epi1(X[M,D] * Wa[F,D]^T); Y[M,D] = epi2(H * Wb[D,F]^T).
+ * Replaces PositionwiseFeedForward.forward (V/models/layers/position_wise_feed_forward.py:12-17) + dropout2 + residual
+ * (V/models/blocks/encoder_layer.py:30-33), and -- with the transposed weight shadows and epi1 = gate -- its data-gradient
+ * chain.  H is written once (backward needs it) and consumed from LDS; results are bit-identical to two
+ * iq_gemm_bf16_nt calls.  epi1: bias / relu / drop / gate; epi2: bias / drop / residual.  D in {64,128,192,256}, F % 128 == 0. */
+int iq_gemm_chain_supported(int D, int F);
+int iq_gemm_bf16_chain(const void* X, int ldx, const void* Wa, int ldwa, void* H, int ldh, const void* Wb, int ldwb,
+                       void* Y, int ldy, int M, int F, int D, const iq_epilogue_t* epi1, const iq_epilogue_t* epi2,
+                       iq_stream_t stream);
+
 /* Weight gradient: dW[N,K] (+)= dY[M,N]^T * X[M,K]; dbias[N] (+)= colsum(dY) (NULL to skip).
  * Split over M into slabs in `ws` (iq_wgrad_ws_bytes), reduced deterministically (no atomics). */
 size_t iq_wgrad_ws_bytes(int M, int N, int K);

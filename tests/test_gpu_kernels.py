@@ -179,6 +179,51 @@ def test_gemm_wave_private_wide_n(L, M, N_, K):
     assert torch.equal((out_s.float() != 0)[sel], keep[:Ms][sel])
 
 
+def _epi(N, **kw):
+    e = N.Epilogue()
+    for k, v in kw.items():
+        if k in ("bias", "gate", "residual"):
+            setattr(e, k, v.data_ptr())
+        elif k == "drop":
+            e.drop = v
+        else:
+            setattr(e, k, v)
+    return e
+
+
+@pytest.mark.parametrize("M,D,F", [(1000, 192, 768), (130, 128, 256), (64, 64, 128), (777, 256, 512), (50432, 192, 768)])
+def test_gemm_chain_equals_two_gemms(L, M, D, F):
+    """iq_gemm_bf16_chain (FFN forward and its data-gradient chain in one launch) is bit-identical to two
+    iq_gemm_bf16_nt calls: same K order, same rounding of the intermediate, same Philox counters."""
+    N = _N()
+    assert L.iq_gemm_chain_supported(D, F) == 1 and L.iq_gemm_chain_supported(176, F) == 0
+    g = torch.Generator(device="cuda").manual_seed(M + D + F)
+    X = bf(torch.randn(M, D, device=dev(), generator=g))
+    Wa = bf(torch.randn(F, D, device=dev(), generator=g) / math.sqrt(D))
+    Wb = bf(torch.randn(D, F, device=dev(), generator=g) / math.sqrt(F))
+    ba, bb = torch.randn(F, device=dev(), generator=g), torch.randn(D, device=dev(), generator=g)
+    R = bf(torch.randn(M, D, device=dev(), generator=g)); G = bf(torch.randn(M, F, device=dev(), generator=g))
+    d1, d2 = _drop(11, 2, 5, 0.1), _drop(11, 2, 6, 0.1)
+    cases = [
+        (dict(bias=ba, relu=1, drop=d1), dict(bias=bb, drop=d2, residual=R, ldr=D)),      # FFN forward, training
+        (dict(bias=ba, relu=1), dict(bias=bb, residual=R, ldr=D)),                         # FFN forward, eval
+        (dict(gate=G, ldg=F, gate_scale=1.0 / 0.9), dict(residual=R, ldr=D)),              # data-gradient chain
+        (dict(), dict()),
+    ]
+    for k1, k2 in cases:
+        e1, e2 = _epi(N, **k1), _epi(N, **k2)
+        H = torch.empty(M, F, dtype=torch.bfloat16, device=dev()); Y = torch.empty(M, D, dtype=torch.bfloat16, device=dev())
+        N.check(L.iq_gemm_bf16_chain(X.data_ptr(), D, Wa.data_ptr(), D, H.data_ptr(), F, Wb.data_ptr(), F, Y.data_ptr(), D,
+                                     M, F, D, C.byref(e1), C.byref(e2), stream()), "chain")
+        H2 = run_gemm(L, X, Wa, M, F, D, **k1)
+        Y2 = run_gemm(L, H2, Wb, M, D, F, **k2)
+        assert torch.equal(H, H2), f"H differs ({list(k1)})"
+        assert torch.equal(Y, Y2), f"Y differs ({list(k2)})"
+    # and against fp64 for the plain case
+    ref = (X.double() @ Wa.double().t()).to(torch.bfloat16).double() @ Wb.double().t()
+    close_bf16(Y, ref, "chain vs fp64")
+
+
 def test_gemm_asymmetric_layout(L):
     """A = I picks out B^T exactly: catches swapped fragment / C-layout maps (guide 3)."""
     K = 64

@@ -35,8 +35,12 @@ struct GemmParams {
 constexpr int EPI_RES = 1, EPI_GATE = 2, EPI_PE = 4;
 
 // row0 / col0: global row / column of the wave's first accumulator tile; the wave owns MT x NT tiles of 16x16.
-template <int MT, int NT, int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][NT], int row0, int col0, int lane) {
+// LDSOUT (chained GEMMs, gemm_chain.hip): the rounded bf16 tile is ALSO left in LDS as the A operand of the next
+// product: [rows][256 B] image at `hs`, 16 B chunk c of row r at chunk c ^ (r & 15); (lrow0, lcol0) = the wave tile's
+// origin inside that image.
+template <int MT, int NT, int EPI, bool LDSOUT = false>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][NT], int row0, int col0, int lane,
+                                              unsigned char* hs = nullptr, int lrow0 = 0, int lcol0 = 0) {
   static_assert(NT % 2 == 0, "column tiles are consumed in pairs");
 #ifdef IQ_EPI_SKIP   // ablation build: timing only
 #pragma unroll
@@ -129,10 +133,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
           for (int e = 0; e < 8; ++e) w[e] += (float)res[i][jp][e];
         }
+        const bf16x8 packed = pack8(w);
+        if (LDSOUT) {
+          const int lr = lrow0 + i * 16 + c16, lc = (lcol0 + (col - col0)) >> 3;
+          *reinterpret_cast<bf16x8*>(hs + lr * 256 + ((lc ^ (lr & 15)) << 4)) = packed;
+        }
 #ifdef IQ_EPI_NO_STORE
         if (p.ldc < 0)
 #endif
-        *reinterpret_cast<bf16x8*>(p.C + orow[i] * p.ldc + col) = pack8(w);
+        *reinterpret_cast<bf16x8*>(p.C + orow[i] * p.ldc + col) = packed;
       }
     }
   }

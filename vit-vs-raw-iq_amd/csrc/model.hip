@@ -580,10 +580,19 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
     const unsigned char* dO2 = tr ? gY : gZ;
     memset(&e, 0, sizeof(e));
     e.gate = ws + a.hid; e.ldg = F; e.gate_scale = dscale;
-    IQ_TRY(iq_gemm_bf16_nt(dO2, D, m->sht(o.t_w2), D, gH, F, M, F, D, &e, stream), "ffn2 dgrad");
-    memset(&e, 0, sizeof(e));
-    e.residual = gZ; e.ldr = D;
-    IQ_TRY(iq_gemm_bf16_nt(gH, F, m->sht(o.t_w1), F, ws + w.gB, D, M, D, F, &e, stream), "ffn1 dgrad");
+    iq_epilogue_t e2;
+    memset(&e2, 0, sizeof(e2));
+    e2.residual = gZ; e2.ldr = D;
+    // FFN data-gradient chain in one launch (iq_gemm_bf16_chain, bit-identical to the two GEMMs): 71.7 vs 78.9 us in
+    // isolation on cfg B, but no gain inside the step (6.65-6.68 vs 6.62-6.64 ms) -- opt-in, IQ_BWD_CHAIN=1.
+    static const bool use_chain = getenv("IQ_BWD_CHAIN") != nullptr;
+    if (use_chain && iq_gemm_chain_supported(D, F) && M >= 64 * 256) {
+      IQ_TRY(iq_gemm_bf16_chain(dO2, D, m->sht(o.t_w2), D, gH, F, m->sht(o.t_w1), F, ws + w.gB, D, M, F, D, &e, &e2, stream),
+             "ffn dgrad chain");
+    } else {
+      IQ_TRY(iq_gemm_bf16_nt(dO2, D, m->sht(o.t_w2), D, gH, F, M, F, D, &e, stream), "ffn2 dgrad");
+      IQ_TRY(iq_gemm_bf16_nt(gH, F, m->sht(o.t_w1), F, ws + w.gB, D, M, D, F, &e2, stream), "ffn1 dgrad");
+    }
     // norm1 backward (+ dropout1 mask)
     const iq_dropout_t dr1 = m->bwd_site(1 + 3 * l, step_dev, tr);
     IQ_TRY(iq_ln_bwd(ws + w.gB, ws + a.z1, (const float*)(ws + a.mean1), (const float*)(ws + a.rstd1), P + o.g1,
