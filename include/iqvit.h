@@ -146,6 +146,13 @@ int iq_attn_bwd(const void* qkv, const void* out, const void* dout, const float*
  * iq_cls_rows writes row 0 of every frame: dropout(cls + pe[0]) (V/models/encoder.py:42-47).
  * iq_embed_bwd_gather compacts d(x0) rows (dropping cls rows, re-applying the dropout mask)
  * into [B*tok, D] for the embedding wgrad and reduces d(cls) = sum_b d(x0)[b,0,:]. */
+/* Input pipeline on the device: raw[n_frames, len, 2] fp32 I/Q frames -> per-channel z-score
+ * (stats = {i_mean, i_std, q_mean, q_std}) -> out[n_frames, 2, take]: the first `take` I samples then the first `take`
+ * Q samples of every frame.  take = len is both reference layouts: viewed as (1, 32, 64) it is the ViT "image" of
+ * V/dataloader/dataset.py:210-224, as (2, len) the transpose of R/dataloader/dataset.py:214-222.  Bit-identical to the
+ * CPU preprocessing (IEEE subtract and divide). */
+int iq_frames_preprocess(const float* raw, float* out, int n_frames, int len, int take, const float* stats,
+                         iq_stream_t stream);
 int iq_patchify(const float* src, void* patches, int kind, int B, int C, int H, int W, int p, int Kpad,
                 iq_stream_t stream);
 int iq_cls_rows(const float* cls, const float* pe, void* x0, int B, int S, int D, const iq_dropout_t* drop,

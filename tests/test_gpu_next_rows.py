@@ -127,3 +127,26 @@ def test_sweep_runs_task_parallel_driver_single_rank():
     assert len(evaluated) == 3 and all(e.shape == (6,) for e in evaluated)
     assert -1.0 <= cost <= 0.0 and np.all(best >= lo) and np.all(best <= hi)
     assert cost == min(e.min() for e in evaluated)
+
+
+@pytest.mark.gpu
+def test_device_input_pipeline_matches_cpu_preprocessing_bitwise():
+    """raw frames -> pinned H2D -> iq_frames_preprocess == the reference's per-frame CPU arithmetic."""
+    import numpy as np, torch
+    from vit_vs_raw_iq_amd import data as D
+    X, Y, Z = D.make_dataset(700, seed=5)
+    st = D.normalization_stats(X, np.arange(len(X)), seed=49, n_subset=500)
+    pv = D.DeviceInputPipeline(st, "vit", batch=256)
+    pr = D.DeviceInputPipeline(st, "rawiq", batch=256)
+    ps = D.DeviceInputPipeline(st, "vit", batch=256, h=32, w=32)        # BASELINE configs[0]: first 512 I and Q samples
+    for lo in (0, 256, 512):                                            # three batches: both staging slots get reused
+        fr = X[lo:lo + 256] if lo < 512 else X[lo:]                     # last batch is short (188 frames)
+        assert torch.equal(pv(fr).cpu(), torch.from_numpy(D.preprocess_reference(fr, st, "vit")))
+        assert torch.equal(pr(fr).cpu(), torch.from_numpy(D.preprocess_reference(fr, st, "rawiq")))
+        assert torch.equal(ps(fr).cpu(), torch.from_numpy(D.preprocess_reference(fr, st, "vit", 32, 32)))
+    # submit / get split: the copy of batch k+1 overlaps whatever runs between them
+    pv.submit(X[:256]); a = pv.get(); pv.submit(X[256:512]); b = pv.get()
+    assert torch.equal(a.cpu(), torch.from_numpy(D.preprocess_reference(X[:256], st, "vit")))
+    assert torch.equal(b.cpu(), torch.from_numpy(D.preprocess_reference(X[256:512], st, "vit")))
+    with pytest.raises(ValueError):
+        D.DeviceInputPipeline(st, "vit", batch=8, h=64, w=64)           # needs 2048 samples per channel

@@ -75,3 +75,48 @@ def test_synthetic_dataset_fields_and_transforms():
     for name in D.CLASSES[:17]:
         c = D.constellation(name)
         assert abs(np.mean(np.abs(c) ** 2) - 1.0) < 1e-9
+
+
+def test_split_indices_is_stratified_disjoint_and_deterministic():
+    """the (modulation x SNR)-stratified split of V/dataloader/utils.py:58-148."""
+    import numpy as np
+    from vit_vs_raw_iq_amd import data as D
+    rng = np.random.default_rng(0)
+    mods = np.array(["BPSK", "QPSK", "8PSK", "16QAM"])
+    labels = np.repeat(mods, 3 * 40)
+    snrs = np.tile(np.repeat(np.array([-4.0, 6.0, 20.0]), 40), 4)
+    perm = rng.permutation(len(labels))
+    labels, snrs = labels[perm], snrs[perm]
+    tr, va, te, lmap = D.split_indices(labels, snrs, ["BPSK", "QPSK", "16QAM"], 0.7, 0.15, 0.15, seed=49)
+    assert lmap == {"BPSK": 0, "QPSK": 1, "16QAM": 2}
+    allidx = np.concatenate([tr, va, te])
+    assert len(np.unique(allidx)) == len(allidx) == 3 * 3 * 40          # disjoint and complete over the target classes
+    assert not np.isin(labels[allidx], ["8PSK"]).any()
+    for mod in ("BPSK", "QPSK", "16QAM"):
+        for snr in (-4.0, 6.0, 20.0):
+            cell = lambda idx: int(((labels[idx] == mod) & (snrs[idx] == snr)).sum())
+            assert (cell(tr), cell(va), cell(te)) == (28, 6, 6)           # 40 -> test 6, then 34 -> valid 6 (sklearn ceil rule)
+    tr2, va2, te2, _ = D.split_indices(labels, snrs, ["BPSK", "QPSK", "16QAM"], 0.7, 0.15, 0.15, seed=49)
+    assert np.array_equal(tr, tr2) and np.array_equal(va, va2) and np.array_equal(te, te2)
+    tr3, _, _, _ = D.split_indices(labels, snrs, ["BPSK", "QPSK", "16QAM"], 0.7, 0.15, 0.15, seed=50)
+    assert not np.array_equal(tr, tr3)
+    import pytest
+    with pytest.raises(ValueError):
+        D.split_indices(labels, snrs, ["BPSK"], 0.7, 0.2, 0.2, seed=1)
+
+
+def test_normalization_stats_and_reference_preprocessing():
+    import numpy as np, torch
+    from vit_vs_raw_iq_amd import data as D
+    X, Y, Z = D.make_dataset(300, seed=3)
+    idx = np.arange(0, 300, 2)
+    st = D.normalization_stats(X, idx, seed=49, n_subset=100)
+    np.random.seed(49)
+    pick = np.sort(np.random.choice(idx, 100, replace=False))
+    sub = torch.from_numpy(X[pick])
+    assert st["i_mean"] == sub[:, :, 0].mean().item() and st["q_std"] == sub[:, :, 1].flatten().std().item()
+    img = D.preprocess_reference(X[:5], st, "vit")
+    seq = D.preprocess_reference(X[:5], st, "rawiq")
+    assert img.shape == (5, 1, 32, 64) and seq.shape == (5, 2, 1024)
+    assert np.array_equal(img.reshape(5, 2, 1024), seq)                 # same numbers, two views ([I;Q] concat == (2, len))
+    assert abs(float(seq[:, 0].mean())) < 0.2

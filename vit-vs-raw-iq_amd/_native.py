@@ -66,6 +66,7 @@ SIGNATURES = {
     "iq_attn_supported": (_I, [_I, _I]),
     "iq_attn_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "iq_attn_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "iq_frames_preprocess": (_I, [_P, _P, _I, _I, _I, C.POINTER(C.c_float), _P]),
     "iq_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "iq_cls_rows": (_I, [_P, _P, _P, _I, _I, _I, C.POINTER(Dropout), _P]),
     "iq_embed_bwd_gather": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, C.POINTER(Dropout), _I, _P]),

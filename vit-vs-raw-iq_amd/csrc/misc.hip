@@ -557,3 +557,35 @@ extern "C" int iq_transpose_cast_bf16(const float* src, void* dst, int rows, int
   transpose_cast_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, (bf16*)dst, rows, cols);
   return iq_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Input pipeline on the device: what SingleStreamImageDataset.__getitem__ does per frame on the CPU workers
+// (V/dataloader/dataset.py:210-224, R/dataloader/dataset.py:214-222): per-channel z-score of the raw (len, 2) I/Q
+// frame, then layout 0: [I(len) ; Q(len)] concatenated (the caller views it as (1, H, W)), layout 1: transpose to
+// (2, len).  One thread per complex sample: an 8 B coalesced read, two 4 B writes at stride len.
+__global__ __launch_bounds__(256) void frames_preprocess_kernel(const float* __restrict__ raw, float* __restrict__ out, long n_samp,
+                                                                int len, int take, float i_mean, float i_std, float q_mean,
+                                                                float q_std) {
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < n_samp; id += (long)gridDim.x * blockDim.x) {
+    const long f = id / take;
+    const int t = (int)(id - f * take);
+    const float2 v = *reinterpret_cast<const float2*>(raw + (f * len + t) * 2);
+    out[f * 2 * take + t] = (v.x - i_mean) / i_std;           // IEEE division: bit-identical to the CPU path
+    out[f * 2 * take + take + t] = (v.y - q_mean) / q_std;
+  }
+}
+
+extern "C" int iq_frames_preprocess(const float* raw, float* out, int n_frames, int len, int take, const float* stats,
+                                    iq_stream_t stream) {
+  if (n_frames <= 0) return IQ_OK;
+  if (!raw || !out || !stats || len <= 0 || take <= 0 || take > len) return IQ_ERR_ARG;
+  if (!(stats[1] > 0.f) || !(stats[3] > 0.f)) return IQ_ERR_ARG;
+  if ((uintptr_t)raw & 7) return IQ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  IQ_PROF(IQ_FAM_MISC, st);
+  const long n = (long)n_frames * take;
+  long nb = (n + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  frames_preprocess_kernel<<<(int)nb, 256, 0, st>>>(raw, out, n, len, take, stats[0], stats[1], stats[2], stats[3]);
+  return iq_launch_status();
+}

@@ -7,6 +7,12 @@ This module generalises that recipe to the 19 class names of ViT/training/train.
 accuracy comparison of BASELINE.json ("top-1 accuracy reproduced on the same synthetic IQ set") has
 a shared, deterministic data source for the GPU path and the CPU oracle.
 
+The input pipeline of SURVEY 8(f) row 4 is here too: `split_indices` (the (modulation x SNR)-stratified 70/15/15 split of
+V|R/dataloader/utils.py:58-148), `normalization_stats` (the 5000-frame I/Q statistics of V/dataloader/dataset.py:116-158)
+and `DeviceInputPipeline` (pinned double-buffered H2D of RAW frames + z-score / layout on the GPU through
+iq_frames_preprocess -- what the reference does per frame in DataLoader worker processes).  The HDF5 reader itself
+(h5py, RadioML file) is not available in this environment and stays out of scope.
+
 Pre-processing mirrors SingleStreamImageDataset.__getitem__:
   z-score per channel with statistics from a 5000-frame subset (ViT/dataloader/dataset.py:116-158,210-213)
   ViT:    [I(1024) ; Q(1024)] -> view(1, 32, 64)           (ViT/dataloader/dataset.py:216-224)
@@ -111,3 +117,132 @@ def to_vit_images(X: np.ndarray, mean, std, h: int = 32, w: int = 64) -> np.ndar
 def to_rawiq(X: np.ndarray, mean, std) -> np.ndarray:
     """(N,1024,2) -> (N,2,1024)."""
     return np.ascontiguousarray(((X - mean) / std).transpose(0, 2, 1)).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Input pipeline with the reference's semantics (SURVEY 8(f) row 4)
+# ----------------------------------------------------------------------------------------------------------------
+def split_indices(labels, snrs, target_mods, train_ratio: float = 0.7, valid_ratio: float = 0.15, test_ratio: float = 0.15,
+                  seed: int = 49):
+    """(train, valid, test) index arrays + label map, stratified by (modulation, SNR) cell.
+
+    Same procedure as `split_data` (V/dataloader/utils.py:58-148): per cell, sklearn `train_test_split` peels off the test
+    share, then the validation share of the remainder, both with `random_state=seed`; the three lists are shuffled at the
+    end with one `np.random.seed(seed)` stream.  `labels` holds modulation names (or ints with `target_mods` = ints)."""
+    from sklearn.model_selection import train_test_split
+    if not np.isclose(train_ratio + valid_ratio + test_ratio, 1.0):
+        raise ValueError("Ratios must sum to 1.0")
+    labels = np.asarray(labels)
+    snrs = np.asarray(snrs)
+    label_map = {mod: i for i, mod in enumerate(target_mods)}
+    rel_valid = valid_ratio / (train_ratio + valid_ratio)
+    parts = ([], [], [])
+    for mod in target_mods:
+        in_mod = labels == mod
+        for snr in np.unique(snrs):
+            cell = np.where(in_mod & (snrs == snr))[0]
+            if len(cell) == 0:
+                continue
+            rest, test = train_test_split(cell, test_size=test_ratio, random_state=seed, shuffle=True)
+            if len(rest) > 1:
+                train, valid = train_test_split(rest, test_size=rel_valid, random_state=seed, shuffle=True)
+            else:
+                train, valid = rest, []
+            for dst, src in zip(parts, (train, valid, test)):
+                dst.extend(src)
+    np.random.seed(seed)
+    for lst in parts:
+        np.random.shuffle(lst)
+    return np.array(parts[0]), np.array(parts[1]), np.array(parts[2]), label_map
+
+
+def normalization_stats(X: np.ndarray, indices, seed: int = 49, n_subset: int = 5000):
+    """{'i_mean','i_std','q_mean','q_std'} over a seeded subset of the training indices, as `_calculate_normalization_stats`
+    (V/dataloader/dataset.py:116-158): `np.random.seed(seed)` + `np.random.choice(indices, n, replace=False)`, fp32 values,
+    torch's unbiased std, std floored at 1e-8."""
+    import torch
+    indices = np.asarray(indices)
+    n = min(n_subset, len(indices))
+    np.random.seed(seed)
+    pick = np.sort(np.random.choice(indices, n, replace=False))
+    sub = torch.from_numpy(np.ascontiguousarray(X[pick])).float()
+    i_all, q_all = sub[:, :, 0].flatten(), sub[:, :, 1].flatten()
+    return {"i_mean": i_all.mean().item(), "i_std": max(i_all.std().item(), 1e-8),
+            "q_mean": q_all.mean().item(), "q_std": max(q_all.std().item(), 1e-8)}
+
+
+def preprocess_reference(frames: np.ndarray, stats: dict, layout: str, h: int = 32, w: int = 64) -> np.ndarray:
+    """CPU statement of __getitem__'s arithmetic for a batch (fp32 throughout), used by tests and the CPU oracle legs."""
+    import torch
+    x = torch.from_numpy(np.ascontiguousarray(frames)).float().clone()
+    x[:, :, 0] = (x[:, :, 0] - stats["i_mean"]) / stats["i_std"]
+    x[:, :, 1] = (x[:, :, 1] - stats["q_mean"]) / stats["q_std"]
+    if layout == "rawiq":
+        return x.transpose(1, 2).contiguous().numpy()
+    take = h * w // 2
+    return torch.cat((x[:, :take, 0], x[:, :take, 1]), dim=1).view(len(frames), 1, h, w).numpy()
+
+
+class DeviceInputPipeline:
+    """Raw I/Q frames -> model input on the GPU.
+
+    The reference normalises and re-lays-out every frame on CPU worker processes and ships the result
+    (`pin_memory=True`, `.to(device, non_blocking=True)`, V/training/train.py:351-364,189-190).  Here the RAW
+    `(B, len, 2)` fp32 frames go into one of two pinned staging buffers, cross PCIe on a copy stream while the previous
+    step computes, and `iq_frames_preprocess` produces the `(B,1,H,W)` ViT image or the `(B,2,len)` raw-IQ tensor on
+    the compute stream.  No CPU fallback: construction fails without the HIP library / a GPU."""
+
+    def __init__(self, stats: dict, layout: str, batch: int, length: int = 1024, h: int = 32, w: int = 64, device="cuda"):
+        import ctypes as C
+        import torch
+        from . import _native as N
+        if layout not in ("vit", "rawiq"):
+            raise ValueError(f"unknown layout: {layout}")
+        self._N, self._L, self._torch = N, N.lib(), torch
+        self.layout, self.length, self.h, self.w = layout, length, h, w
+        self.take = length if layout == "rawiq" else h * w // 2
+        if self.take > length:
+            raise ValueError(f"image {h}x{w} needs {self.take} samples per channel, frames have {length}")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise N.IqError("DeviceInputPipeline needs a CUDA/HIP device (no CPU fallback)")
+        self._stats = (C.c_float * 4)(stats["i_mean"], stats["i_std"], stats["q_mean"], stats["q_std"])
+        self._host = [torch.empty(batch, length, 2, dtype=torch.float32).pin_memory() for _ in range(2)]
+        self._dev = [torch.empty(batch, length, 2, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self._ready = [torch.cuda.Event(), torch.cuda.Event()]
+        self._free = [torch.cuda.Event(), torch.cuda.Event()]
+        self._copy = torch.cuda.Stream(device=self.device)
+        self._slot = 0
+        self._pending = None
+
+    def submit(self, frames: np.ndarray):
+        """Start moving a batch of raw frames to the GPU (returns immediately)."""
+        torch = self._torch
+        s = self._slot
+        n = len(frames)
+        self._free[s].synchronize()                       # the preprocess that last read this slot has been issued and run
+        self._host[s][:n].copy_(torch.from_numpy(np.ascontiguousarray(frames, dtype=np.float32)))
+        with torch.cuda.stream(self._copy):
+            self._dev[s][:n].copy_(self._host[s][:n], non_blocking=True)
+            self._ready[s].record(self._copy)
+        self._pending = (s, n)
+        self._slot ^= 1
+
+    def get(self):
+        """The submitted batch as the model's input tensor (on the current stream)."""
+        torch = self._torch
+        if self._pending is None:
+            raise RuntimeError("get() without a submitted batch")
+        s, n = self._pending
+        self._pending = None
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(self._ready[s])
+        out = torch.empty(n, 2, self.take, dtype=torch.float32, device=self.device)
+        self._N.check(self._L.iq_frames_preprocess(self._dev[s].data_ptr(), out.data_ptr(), n, self.length, self.take,
+                                                   self._stats, cur.cuda_stream), "iq_frames_preprocess")
+        self._free[s].record(cur)
+        return out.view(n, 1, self.h, self.w) if self.layout == "vit" else out
+
+    def __call__(self, frames: np.ndarray):
+        self.submit(frames)
+        return self.get()
