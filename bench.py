@@ -206,11 +206,19 @@ def main():
 
     geo = geometry(kind, kw)
     roof = None
+    if world > 1 and not a.no_roofline:
+        # every rank must take the same number of steps (each step all-reduces): the profiled leg runs everywhere,
+        # only rank 0 times its kernels
+        if rank != 0:
+            tr.use_graph = False
+            for _ in range(1 + a.prof_steps):
+                tr.step(x, y)
+            torch.cuda.synchronize()
     if rank == 0 and not a.no_roofline:
         # profiled leg: same workload, eager launches, HIP event pair around every kernel-family call
         L = N.lib()
         tr.use_graph = False
-        ms = (C_double8 := (__import__("ctypes").c_double * 8))()
+        ms = (__import__("ctypes").c_double * 8)()
         cnt = (__import__("ctypes").c_longlong * 8)()
         tr.step(x, y)
         torch.cuda.synchronize()
@@ -280,6 +288,7 @@ def main():
         }
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
