@@ -249,12 +249,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const bf16* __res
   // ---- stage Q, dO; delta[q] = sum_d dO*O; lse ------------------------------------------------
   stage_rows<DH>(I0, qb, ldg, 0, spad, S, tid);
   stage_rows<DH>(I1, dob, (long)D, 0, spad, S, tid);
+  __syncthreads();
+  // delta from the dO image just staged (dO is fetched from HBM once, not twice); O comes from HBM, its only use
   for (int q = tid; q < spad; q += ATT_THREADS) {
     float dl = 0.f, ls = 0.f;
     if (q < S) {
 #pragma unroll
       for (int c = 0; c < C::CPR; ++c) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(dob + (long)q * D + c * 8);
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(I1 + q * C::LD + c * 8);
         const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(ob + (long)q * D + c * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dl += (float)a[e] * (float)o8[e];
@@ -324,20 +326,32 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const bf16* __res
   }
 
   // ---- phase B: restage K, V; wave owns 32 queries, sweeps keys; dQ^T in registers ---------------
+  // The wave's query-side fragments (its first query block) come out of the Q / dO images before K and V overwrite
+  // them: Q and dO are fetched from HBM once.  (S > 256: later blocks of a wave fall back to global loads.)
+  bf16x8 qf[2][C::KS], dof[2][C::KS];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s) {
+      const int q = min(wave, nblk - 1) * 32 + u * 16 + c16;
+      qf[u][s] = row_frag_lds<DH>(I0, q, s, lane);
+      dof[u][s] = row_frag_lds<DH>(I1, q, s, lane);
+    }
   __syncthreads();
   stage_rows<DH>(I0, kb_, ldg, 0, spad, S, tid);
   stage_rows<DH>(I1, vb_, ldg, 0, spad, S, tid);
   __syncthreads();
   for (int qblk = wave; qblk < nblk; qblk += ATT_WAVES) {
-    bf16x8 qf[2][C::KS], dof[2][C::KS];
     float lq[2], dl[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int q = qblk * 32 + u * 16 + c16;
+      if (qblk != wave) {
 #pragma unroll
-      for (int s = 0; s < C::KS; ++s) {
-        qf[u][s] = row_frag_gmem<DH>(qb, ldg, q, S, s, lane);
-        dof[u][s] = row_frag_gmem<DH>(dob, (long)D, q, S, s, lane);
+        for (int s = 0; s < C::KS; ++s) {
+          qf[u][s] = row_frag_gmem<DH>(qb, ldg, q, S, s, lane);
+          dof[u][s] = row_frag_gmem<DH>(dob, (long)D, q, S, s, lane);
+        }
       }
       lq[u] = lse_s[q];
       dl[u] = del_s[q];
