@@ -35,13 +35,56 @@ struct GemmParams {
 constexpr int EPI_RES = 1, EPI_GATE = 2, EPI_PE = 4;
 
 // row0 / col0: global row / column of the wave's first accumulator tile; the wave owns MT x NT tiles of 16x16.
+// The tail is split in two (gemm_epilogue = epi_load + vmcnt(0) + epi_finish) so that a kernel may place the loads
+// elsewhere.  Measured: issuing them BEFORE the K loop of the tiled kernel (so that the epilogue never waits) is slower
+// (gemm_nt 3.32 vs 3.14 ms/step; gate variant 52 vs 45 us): vmcnt is in-order, so the first operand stage then waits
+// behind 16-32 KB of residual / gate per workgroup.
+template <int MT, int NT, int EPI>
+struct EpiRegs {
+  static constexpr int NP = NT / 2;
+  f32x4 bias_lo[NP], bias_hi[NP];
+  bf16x8 res[(EPI & EPI_RES) ? MT : 1][NP], gt[(EPI & EPI_GATE) ? MT : 1][NP];
+};
+
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void epi_load(const GemmParams& p, EpiRegs<MT, NT, EPI>& R, int row0, int col0, int lane) {
+  static_assert(NT % 2 == 0, "column tiles are consumed in pairs");
+  constexpr int NP = NT / 2;
+  const int g = lane >> 4, c16 = lane & 15;
+  const bool odd = (g & 1) != 0;
+#pragma unroll
+  for (int jp = 0; jp < NP; ++jp) {
+    const int col = col0 + (odd ? (2 * jp + 1) * 16 + 4 * (g - 1) : (2 * jp) * 16 + 4 * g);
+    R.bias_lo[jp] = f32x4{0.f, 0.f, 0.f, 0.f};
+    R.bias_hi[jp] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias && col < p.N) {
+      R.bias_lo[jp] = *reinterpret_cast<const f32x4*>(p.bias + col);
+      R.bias_hi[jp] = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int gm = row0 + i * 16 + c16;
+      const bool ok = gm < p.M && col < p.N;
+      if (EPI & EPI_RES) {
+        long orow = gm;
+        if (EPI & EPI_PE) { const int f = gm / p.tok; orow = (long)f * p.seq + (gm - f * p.tok) + p.cls_off; }
+        R.res[i][jp] = bf16x8{};
+        if (ok) R.res[i][jp] = *reinterpret_cast<const bf16x8*>(p.residual + orow * p.ldr + col);
+      }
+      if (EPI & EPI_GATE) {
+        R.gt[i][jp] = bf16x8{};
+        if (ok) R.gt[i][jp] = *reinterpret_cast<const bf16x8*>(p.gate + (long)gm * p.ldg + col);
+      }
+    }
+  }
+}
+
 // LDSOUT (chained GEMMs, gemm_chain.hip): the rounded bf16 tile is ALSO left in LDS as the A operand of the next
 // product: [rows][256 B] image at `hs`, 16 B chunk c of row r at chunk c ^ (r & 15); (lrow0, lcol0) = the wave tile's
 // origin inside that image.
 template <int MT, int NT, int EPI, bool LDSOUT = false>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][NT], int row0, int col0, int lane,
-                                              unsigned char* hs = nullptr, int lrow0 = 0, int lcol0 = 0) {
-  static_assert(NT % 2 == 0, "column tiles are consumed in pairs");
+__device__ __forceinline__ void epi_finish(const GemmParams& p, f32x4 (&acc)[MT][NT], const EpiRegs<MT, NT, EPI>& R, int row0,
+                                           int col0, int lane, unsigned char* hs = nullptr, int lrow0 = 0, int lcol0 = 0) {
 #ifdef IQ_EPI_SKIP   // ablation build: timing only
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -53,49 +96,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
   const int g = lane >> 4, c16 = lane & 15;
   const bool odd = (g & 1) != 0;
   const IqRng rng = p.drop_on ? rng_resolve(p.rng) : p.rng;
-  int colp[NP];
-  f32x4 bias_lo[NP], bias_hi[NP];
-  long orow[MT];
-  int prow[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int gm = row0 + i * 16 + c16;
-    orow[i] = gm;
-    prow[i] = 0;
+    long orow = gm;
+    int prow = 0;
     if (EPI & EPI_PE) {
       const int f = gm / p.tok, tk = gm - f * p.tok;
-      prow[i] = tk + p.cls_off;
-      orow[i] = (long)f * p.seq + prow[i];
+      prow = tk + p.cls_off;
+      orow = (long)f * p.seq + prow;
     }
-  }
-  bf16x8 res[(EPI & EPI_RES) ? MT : 1][NP], gt[(EPI & EPI_GATE) ? MT : 1][NP];
-#pragma unroll
-  for (int jp = 0; jp < NP; ++jp) {
-    colp[jp] = col0 + (odd ? (2 * jp + 1) * 16 + 4 * (g - 1) : (2 * jp) * 16 + 4 * g);
-    bias_lo[jp] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bias_hi[jp] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias && colp[jp] < p.N) {
-      bias_lo[jp] = *reinterpret_cast<const f32x4*>(p.bias + colp[jp]);
-      bias_hi[jp] = *reinterpret_cast<const f32x4*>(p.bias + colp[jp] + 4);
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int gm = row0 + i * 16 + c16;
-      const bool ok = gm < p.M && colp[jp] < p.N;
-      if (EPI & EPI_RES) {
-        res[i][jp] = bf16x8{};
-        if (ok) res[i][jp] = *reinterpret_cast<const bf16x8*>(p.residual + orow[i] * p.ldr + colp[jp]);
-      }
-      if (EPI & EPI_GATE) {
-        gt[i][jp] = bf16x8{};
-        if (ok) gt[i][jp] = *reinterpret_cast<const bf16x8*>(p.gate + (long)gm * p.ldg + colp[jp]);
-      }
-    }
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): every load above has landed; none below (PE variant excepted)
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int gm = row0 + i * 16 + c16;
 #pragma unroll
     for (int jp = 0; jp < NP; ++jp) {
       float w[8];
@@ -105,33 +115,33 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         //  read element 0 for every r)
         const float va = acc[i][2 * jp][r], vb = acc[i][2 * jp + 1][r];
         const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
-        w[r] = __uint_as_float(sw[0]) + bias_lo[jp][r];
-        w[4 + r] = __uint_as_float(sw[1]) + bias_hi[jp][r];
+        w[r] = __uint_as_float(sw[0]) + R.bias_lo[jp][r];
+        w[4 + r] = __uint_as_float(sw[1]) + R.bias_hi[jp][r];
       }
-      const int col = colp[jp];
+      const int col = col0 + (odd ? (2 * jp + 1) * 16 + 4 * (g - 1) : (2 * jp) * 16 + 4 * g);
       if (gm < p.M && col < p.N) {
         if (p.relu) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) w[e] = fmaxf(w[e], 0.f);
         }
         if (EPI & EPI_PE) {
-          const f32x4 pa = *reinterpret_cast<const f32x4*>(p.pe + (long)prow[i] * p.N + col);
-          const f32x4 pb = *reinterpret_cast<const f32x4*>(p.pe + (long)prow[i] * p.N + col + 4);
+          const f32x4 pa = *reinterpret_cast<const f32x4*>(p.pe + (long)prow * p.N + col);
+          const f32x4 pb = *reinterpret_cast<const f32x4*>(p.pe + (long)prow * p.N + col + 4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) { w[e] += pa[e]; w[4 + e] += pb[e]; }
         }
         if (p.drop_on) {
-          const uint32_t keep = dropout_keep8(rng, (uint64_t)(orow[i] * p.N + col) >> 3, p.thresh);
+          const uint32_t keep = dropout_keep8(rng, (uint64_t)(orow * p.N + col) >> 3, p.thresh);
 #pragma unroll
           for (int e = 0; e < 8; ++e) w[e] = ((keep >> e) & 1u) ? w[e] * p.dscale : 0.f;
         }
         if (EPI & EPI_GATE) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) w[e] = ((float)gt[i][jp][e] > 0.f) ? w[e] * p.gate_scale : 0.f;
+          for (int e = 0; e < 8; ++e) w[e] = ((float)R.gt[i][jp][e] > 0.f) ? w[e] * p.gate_scale : 0.f;
         }
         if (EPI & EPI_RES) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) w[e] += (float)res[i][jp][e];
+          for (int e = 0; e < 8; ++e) w[e] += (float)R.res[i][jp][e];
         }
         const bf16x8 packed = pack8(w);
         if (LDSOUT) {
@@ -141,9 +151,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #ifdef IQ_EPI_NO_STORE
         if (p.ldc < 0)
 #endif
-        *reinterpret_cast<bf16x8*>(p.C + orow[i] * p.ldc + col) = packed;
+        *reinterpret_cast<bf16x8*>(p.C + orow * p.ldc + col) = packed;
       }
     }
   }
 }
 
+template <int MT, int NT, int EPI, bool LDSOUT = false>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][NT], int row0, int col0, int lane,
+                                              unsigned char* hs = nullptr, int lrow0 = 0, int lcol0 = 0) {
+  EpiRegs<MT, NT, EPI> R;
+  epi_load<MT, NT, EPI>(p, R, row0, col0, lane);
+  __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): every load above has landed; none below (PE variant excepted)
+  epi_finish<MT, NT, EPI, LDSOUT>(p, acc, R, row0, col0, lane, hs, lrow0, lcol0);
+}
