@@ -193,8 +193,9 @@ def _epi(N, **kw):
 
 @pytest.mark.parametrize("M,D,F", [(1000, 192, 768), (130, 128, 256), (64, 64, 128), (777, 256, 512), (50432, 192, 768)])
 def test_gemm_chain_equals_two_gemms(L, M, D, F):
-    """iq_gemm_bf16_chain (FFN forward and its data-gradient chain in one launch) is bit-identical to two
-    iq_gemm_bf16_nt calls: same K order, same rounding of the intermediate, same Philox counters."""
+    """iq_gemm_bf16_chain (FFN forward and its data-gradient chain in one launch) against two iq_gemm_bf16_nt calls:
+    same K order, same rounding of the intermediate, same Philox counters => bit-identical (the residual-only second
+    GEMM excepted, see below)."""
     N = _N()
     assert L.iq_gemm_chain_supported(D, F) == 1 and L.iq_gemm_chain_supported(176, F) == 0
     g = torch.Generator(device="cuda").manual_seed(M + D + F)
@@ -218,10 +219,35 @@ def test_gemm_chain_equals_two_gemms(L, M, D, F):
         H2 = run_gemm(L, X, Wa, M, F, D, **k1)
         Y2 = run_gemm(L, H2, Wb, M, D, F, **k2)
         assert torch.equal(H, H2), f"H differs ({list(k1)})"
-        assert torch.equal(Y, Y2), f"Y differs ({list(k2)})"
+        if "bias" in k2 or not k2:
+            assert torch.equal(Y, Y2), f"Y differs ({list(k2)})"
+        else:   # residual only: the separate GEMM streams R as K stages (last add inside the MFMA): rounding ties may differ
+            dy = (Y.float() - Y2.float()).abs()
+            assert (dy > 0).float().mean().item() < 1e-4 and (dy <= 2.0 ** -7 * Y2.float().abs() + 1e-6).all()
     # and against fp64 for the plain case
     ref = (X.double() @ Wa.double().t()).to(torch.bfloat16).double() @ Wb.double().t()
     close_bf16(Y, ref, "chain vs fp64")
+
+
+@pytest.mark.parametrize("M,K", [(5000, 768), (130, 576), (50432, 768), (999, 384)])
+def test_gemm_residual_as_k_stages(L, M, K):
+    """C = A W^T + R with N = 192 and nothing else in the tail takes the 192-column tile with the residual streamed as
+    extra K stages against identity fragments: must be bit-identical to the ordinary epilogue path (forced here by a
+    zero bias, which disables the shortcut) and match fp64."""
+    N_ = 192
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    A = bf(torch.randn(M, K, device=dev(), generator=g))
+    B = bf(torch.randn(N_, K, device=dev(), generator=g) / math.sqrt(K))
+    Rbig = bf(torch.randn(M, N_ + 64, device=dev(), generator=g))
+    R = Rbig[:, :N_]                                                    # ldr > N
+    out = run_gemm(L, A, B, M, N_, K, residual=R, ldr=N_ + 64)
+    ref = run_gemm(L, A, B, M, N_, K, residual=R, ldr=N_ + 64, bias=torch.zeros(N_, device=dev()))
+    # the last fp32 add happens inside the MFMA here and in the VALU there: same value up to the final bf16 rounding,
+    # which may break a tie the other way for a handful of elements
+    diff = (out.float() - ref.float()).abs()
+    assert (diff > 0).float().mean().item() < 1e-4
+    assert (diff <= 2.0 ** -7 * ref.float().abs() + 1e-6).all()
+    close_bf16(out, A.double() @ B.double().t() + R.double(), "residual-as-K vs fp64")
 
 
 def test_gemm_asymmetric_layout(L):

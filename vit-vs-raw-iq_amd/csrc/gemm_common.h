@@ -44,6 +44,7 @@ struct EpiRegs {
   static constexpr int NP = NT / 2;
   f32x4 bias_lo[NP], bias_hi[NP];
   bf16x8 res[(EPI & EPI_RES) ? MT : 1][NP], gt[(EPI & EPI_GATE) ? MT : 1][NP];
+  IqRng rng;      // resolved here: rng_resolve may LOAD the device-resident step, which must sit before the one wait
 };
 
 template <int MT, int NT, int EPI>
@@ -52,6 +53,7 @@ __device__ __forceinline__ void epi_load(const GemmParams& p, EpiRegs<MT, NT, EP
   constexpr int NP = NT / 2;
   const int g = lane >> 4, c16 = lane & 15;
   const bool odd = (g & 1) != 0;
+  R.rng = p.drop_on ? rng_resolve(p.rng) : p.rng;
 #pragma unroll
   for (int jp = 0; jp < NP; ++jp) {
     const int col = col0 + (odd ? (2 * jp + 1) * 16 + 4 * (g - 1) : (2 * jp) * 16 + 4 * g);
@@ -95,7 +97,7 @@ __device__ __forceinline__ void epi_finish(const GemmParams& p, f32x4 (&acc)[MT]
   constexpr int NP = NT / 2;       // column-tile pairs
   const int g = lane >> 4, c16 = lane & 15;
   const bool odd = (g & 1) != 0;
-  const IqRng rng = p.drop_on ? rng_resolve(p.rng) : p.rng;
+  const IqRng rng = R.rng;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int gm = row0 + i * 16 + c16;

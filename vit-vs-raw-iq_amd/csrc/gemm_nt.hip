@@ -137,7 +137,12 @@ __device__ __forceinline__ int swz64(int row) { return (0x78 >> (((row >> 2) & 3
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 
-template <int BMT, int BN, int EPI>
+// RESK ("residual as K"): for C = A W^T + R with no bias / activation / dropout (the data-gradient GEMMs) and a tile that
+// spans the whole row (BN == N), R is streamed through the SAME ring as BN/32 extra K stages and accumulated by MFMAs
+// against identity fragments built in registers: acc += R * I.  Exact (x * 1.0 and the same final fp32 add as the
+// epilogue's `+ residual`), and the epilogue has no loads left -- what made the 192-column tile lose 9-12 us per launch
+// to an exposed residual fetch (2 workgroups per CU) now arrives prefetched like any operand stage.
+template <int BMT, int BN, int EPI, bool RESK = false>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmParams p) {
   constexpr int BK2 = 32;
   constexpr int WN = BN / 2, NT = WN / 16, MT = BMT / 32;   // wave tile = BMT/2 rows x BN/2 cols
@@ -176,8 +181,34 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
     const int gn = min(n0 + row, p.N - 1);
     b_src[i] = p.B + (long)gn * p.ldb + (pch ^ swz64(row)) * 8;
   }
+  const int nk = p.K / BK2;
+  const int ntot = nk + (RESK ? BN / BK2 : 0);
+  const bf16* r_src[A_LD];
+  bf16x8 idf[2];
+  if (RESK) {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int row = (wave * A_LD + i) * 16 + prow;
+      const int gm = min(m0 + row, p.M - 1);
+      r_src[i] = p.residual + (long)gm * p.ldr + (pch ^ swz64(row)) * 8;
+    }
+    // identity fragments (the weight-side MFMA operand): lane (n = lane & 15, k = 8 (lane >> 4) + e) of the 16-column
+    // tile h of a 32-wide residual stage holds 1 where 16 h + n == k
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int estar = 16 * h + (lane & 15) - 8 * (lane >> 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) idf[h][e] = (bf16)(e == estar ? 1.0f : 0.0f);
+    }
+  }
   auto issue = [&](int ks) {
     unsigned char* st = smem + (ks % NS) * STAGE_BYTES;
+    if (RESK && ks >= nk) {             // a residual stage: rows of R in the A half, nothing in the B half
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i)
+        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(r_src[i] + (ks - nk) * BK2), (lds_void_t*)(st + (wave * A_LD + i) * 1024), 16, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < A_LD; ++i)
       __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(a_src[i] + ks * BK2), (lds_void_t*)(st + (wave * A_LD + i) * 1024), 16, 0, 0);
@@ -199,23 +230,28 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
     for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(8);
   }
   IQ_STAMP(0);
-  const int nk = p.K / BK2;
   issue(0);
-  if (nk > 1) issue(1);
-  for (int ks = 0; ks < nk; ++ks) {
-    if (ks + 1 < nk) {
-      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER_STAGE) : "memory");   // all but the youngest stage have landed
+  if (ntot > 1) issue(1);
+  // head of every stage: this wave's pieces of stage ks have landed (the youngest stage stays in flight), everyone's
+  // have (barrier, which also says stage ks-1 is no longer read), the slot ks-1 vacated is refilled
+  auto stage_begin = [&](int ks) {
+    if (ks + 1 < ntot) {
+      if (!RESK || ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER_STAGE) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A_LD) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();      // stage ks landed for every wave; everyone is done reading stage ks-1
+    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (ks + 2 < ntot) issue(ks + 2);
+  };
+  const int ch = lane >> 4;
+  for (int ks = 0; ks < nk; ++ks) {
+    stage_begin(ks);
     if (ks == 0) IQ_STAMP(1);
-    if (ks + 2 < nk) issue(ks + 2);    // refills the slot stage ks-1 just vacated
     const bf16* As = reinterpret_cast<const bf16*>(smem + (ks % NS) * STAGE_BYTES);
     const bf16* Bs = As + BMT * BK2;
     bf16x8 af[MT], bfr[NT];
-    const int ch = lane >> 4;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int row = wm * (BMT / 2) + i * 16 + (lane & 15);
@@ -239,9 +275,35 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile: see gemm_epilogue
 #endif
   }
+  if (RESK) {
+    // residual stage t covers columns [32 t, 32 t + 32) = column tiles 2t and 2t+1 of the row: the wave that owns them
+    // (wn == 2t / NT) accumulates R * I into exactly those two tiles.  Fully unrolled: every accumulator index is static
+    // (one loop with a run-time tile index made the compiler shuttle all accumulators through copies every K step).
+    constexpr int NRS = BN / BK2;
+#pragma unroll
+    for (int t = 0; t < NRS; ++t) {
+      stage_begin(nk + t);
+      const bf16* As = reinterpret_cast<const bf16*>(smem + ((nk + t) % NS) * STAGE_BYTES);
+      if (wn == (2 * t) / NT) {
+        bf16x8 af[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int row = wm * (BMT / 2) + i * 16 + (lane & 15);
+          af[i] = *reinterpret_cast<const bf16x8*>(As + row * BK2 + (ch ^ swz64(row)) * 8);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int jbase = (2 * t) % NT;      // compile-time after unrolling
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            acc[i][jbase + h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(idf[h], af[i], acc[i][jbase + h], 0, 0, 0);
+        }
+      }
+    }
+  }
   IQ_STAMP(2);
   IQ_STAMP(3);
-  gemm_epilogue<MT, NT, EPI>(p, acc, m0 + (wave >> 1) * (BMT / 2), n0 + (wave & 1) * (BN / 2), lane);
+  gemm_epilogue<MT, NT, RESK ? (EPI & ~EPI_RES) : EPI>(p, acc, m0 + (wave >> 1) * (BMT / 2), n0 + (wave & 1) * (BN / 2), lane);
   IQ_STAMP(4);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   IQ_STAMP(5);
@@ -304,6 +366,17 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   if (p.bias && ((uintptr_t)p.bias % 16)) return IQ_ERR_ARG;
   static const int stagger = getenv("IQ_GEMM_STAGGER") ? atoi(getenv("IQ_GEMM_STAGGER")) : 2;   // measured best of {0,2,6}
   p.stagger = stagger;
+  // C = A W^T + R, nothing else in the tail, whole rows in one 192-column tile: residual streamed as extra K stages.
+  // (the plain 192-column tile reads A once -- N=192 K=768: 27.6 vs 37.3 us -- but lost it all to an exposed residual fetch)
+  static const bool no_resk = getenv("IQ_GEMM_NO_RESK") != nullptr;
+  if (!no_resk && async_ok && epi_mode == EPI_RES && N == 192 && K >= 384 && !p.bias && !p.relu && !p.drop_on &&
+      ((uintptr_t)p.residual % 16) == 0) {
+    p.tiles_m = (M + BM - 1) / BM;
+    p.tiles_n = 1;
+    const size_t lds = (size_t)3 * (BM + 192) * 32 * 2;     // 60 KiB: under the 64 KiB default cap, no attribute call
+    gemm_nt_async_kernel<128, 192, EPI_RES, true><<<p.tiles_m, GEMM_THREADS, lds, st>>>(p);
+    return iq_launch_status();
+  }
   // The weight-stationary persistent kernel (gemm_ws.hip) is correct but measured 5-25 % SLOWER than the tiled
   // kernels on the ViT-Tiny shapes (one 8-wave workgroup per CU serialises its own phases): opt-in only.
   // Wide-N, K <= 192: wave-private kernel with the weight block in registers (gemm_wp.hip); measured equal to the
