@@ -519,6 +519,32 @@ def test_attention_limits(L):
     assert L.iq_attn_supported(64, 48) == 0
 
 
+def test_attention_all_scores_very_negative_stays_finite(L):
+    """Rows whose scores are all << 0 have a very negative LSE: exp2(0 - lse) on a padding key overflows fp32.  The
+    backward masks padding keys (and only those), so nothing non-finite may reach dQ / dK / dV."""
+    N = _N()
+    S, H, dh, Bf = 197, 3, 64, 2
+    D = H * dh
+    qkv = torch.empty(Bf * S, 3 * D, device=dev())
+    g = torch.Generator(device="cuda").manual_seed(7)
+    qkv[:, :D] = 6.0 + 0.1 * torch.randn(Bf * S, D, device=dev(), generator=g)          # q . k = -64 * 36 / 8 = -288
+    qkv[:, D:2 * D] = -6.0 + 0.1 * torch.randn(Bf * S, D, device=dev(), generator=g)
+    qkv[:, 2 * D:] = torch.randn(Bf * S, D, device=dev(), generator=g)
+    qkv = bf(qkv)
+    out = torch.empty(Bf * S, D, dtype=torch.bfloat16, device=dev()); lse = torch.empty(Bf, H, S, device=dev())
+    N.check(L.iq_attn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), Bf, S, H, dh, stream()), "attn_fwd")
+    assert lse.max().item() < -150
+    dout = bf(torch.randn(Bf * S, D, device=dev(), generator=g)); dqkv = torch.empty_like(qkv)
+    N.check(L.iq_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), Bf, S, H, dh,
+                          stream()), "attn_bwd")
+    assert torch.isfinite(out.float()).all() and torch.isfinite(dqkv.float()).all()
+    qr = qkv.double().requires_grad_(True)
+    oref, _ = attn_ref(qr, Bf, S, H, dh)
+    oref.backward(dout.double())
+    close_bf16(out, oref.detach(), "out", rel=2 ** -6)
+    close_bf16(dqkv, qr.grad, "dqkv", rel=2 ** -5, abs_=2e-2 * qr.grad.abs().max().item())
+
+
 # ------------------------------------------------------------------------------------------------
 # embedding front end, head, loss, optimizer
 # ------------------------------------------------------------------------------------------------

@@ -34,6 +34,11 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float NEG_BIG = -1.0e30f;
 
+// exp2 for softmax arguments (<= 0 after the max / LSE subtraction): the bare v_exp_f32.  exp2f() wraps it in a
+// denormal-range fix-up (compare, select, add, select, ldexp: five extra VALU instructions per value) that only matters
+// for results below 2^-126, which are zero for every purpose here -- and the attention kernels are VALU-bound.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 template <int DH> struct AttCfg {
   static constexpr int LD = (DH == 16) ? 16 : DH + 16;  // LDS row stride (elements)
   static constexpr int KS = (DH + 31) / 32;              // 32-deep contraction steps over d
@@ -173,14 +178,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16* __res
               }
             mx = group4_max(mx);
             const float mn = fmaxf(m[u], mx);
-            const float alpha = exp2f(m[u] - mn);
+            const float alpha = fast_exp2(m[u] - mn);
             m[u] = mn;
             float rs = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const float pv = exp2f(sc[u][kt][r] - mn);
+                const float pv = fast_exp2(sc[u][kt][r] - mn);
                 sc[u][kt][r] = pv;
                 rs += pv;
               }
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const bf16* __res
   // ---- phase A: wave owns 16 keys, sweeps queries; dV^T, dK^T in registers ---------------------
   // (16-key units keep the kernel at <= 128 VGPRs, so two 8-wave workgroups share a CU and one's staging /
   //  dependency stalls overlap the other's MFMAs; 32-key units needed 195 VGPRs = one workgroup per CU.)
-  const int nunit = spad / 16;
+  const int nunit = (S + 15) / 16;      // units made only of padding keys are skipped
   for (int unit = wave; unit < nunit; unit += ATT_WAVES) {
     bf16x8 kf[C::KS], vf[C::KS];
 #pragma unroll
@@ -283,6 +288,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const bf16* __res
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) { dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const int key = unit * 16 + c16;
+    const bool unit_partial = unit * 16 + 16 > S;       // wave-uniform
     for (int qblk = 0; qblk < nblk; ++qblk) {
       f32x4 p[2], ds[2];   // [u]
 #pragma unroll
@@ -298,8 +304,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const bf16* __res
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int q = qblk * 32 + u * 16 + 4 * g + r;
-          float pv = exp2f(sa[r] * scale_log2 - lse_s[q]);
-          pv = (key < S && q < S) ? pv : 0.f;
+          // Padded QUERY rows need no mask: Q = dO = 0 and lse = delta = 0 there, so P = 1 and dS = 0 multiply zeros.
+          // Padded KEYS do (only this wave's unit can hold them): P = exp2(-lse) is unbounded when a row's scores are
+          // all very negative, and inf * 0 would poison dQ.
+          float pv = fast_exp2(sa[r] * scale_log2 - lse_s[q]);
+          if (unit_partial) pv = key < S ? pv : 0.f;
           p[u][r] = pv;
           ds[u][r] = pv * (dp[r] - del_s[q]) * scale;
         }
@@ -362,6 +371,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const bf16* __res
 #pragma unroll
       for (int u = 0; u < 2; ++u) dq[dt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int kblk = 0; kblk < nblk; ++kblk) {
+      const bool kblk_partial = kblk * 32 + 32 > S;     // wave-uniform
       f32x4 ds[2][2];  // [u][kt]
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
@@ -379,12 +389,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const bf16* __res
             sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[s], qf[u][s], sa, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[s], dof[u][s], dp, 0, 0, 0);
           }
-          const int q = qblk * 32 + u * 16 + c16;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = kblk * 32 + kt * 16 + 4 * g + r;
-            float pv = exp2f(sa[r] * scale_log2 - lq[u]);
-            pv = (key < S && q < S) ? pv : 0.f;
+            float pv = fast_exp2(sa[r] * scale_log2 - lq[u]);
+            if (kblk_partial) pv = key < S ? pv : 0.f;          // padded keys: see phase A
             ds[u][kt][r] = pv * (dp[r] - dl[u]) * scale;
           }
         }
