@@ -233,6 +233,7 @@ WsPlan plan_ws(const iq_model* m, int B) {
     g[2].N = (int)D; g[2].K = (int)D;
     g[3].N = (int)(3 * D); g[3].K = (int)D;
     mx(iq_wgrad_grouped_ws_bytes(g, 4, (int)M, 0));
+    for (int k = 0; k < 4; ++k) mx(iq_wgrad_grouped_ws_bytes(g + k, 1, (int)M, 0));
     mx(iq_wgrad_grouped_ws_bytes(g, 4, (int)M, bwd_overlap_budget()));
   }
   mx(iq_wgrad_ws_bytes((int)MT, (int)D, m->Ppad));
@@ -571,6 +572,10 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
       pending[par] = false;
     }
     iq_epilogue_t e;
+    // IQ_WGRAD_UNGROUPED=1 (experiment, measured 6.35 vs 6.15-6.22 ms/step, i.e. worse): each weight gradient right
+    // after the data-gradient GEMM that read the same dY, while that operand is still in the 256 MB Infinity Cache,
+    // instead of one grouped launch at the end of the layer
+    static const bool ungrouped = getenv("IQ_WGRAD_UNGROUPED") != nullptr;
     // norm2 backward (+ regenerated dropout2 mask)
     const iq_dropout_t dr2 = m->bwd_site(3 + 3 * l, step_dev, tr);
     float* lp2 = (float*)(ws + w.ln_part[par][0]);
@@ -578,6 +583,20 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
     IQ_TRY(iq_ln_bwd(ws + w.gA, ws + a.z2, (const float*)(ws + a.mean2), (const float*)(ws + a.rstd2), P + o.g2,
                      gZ, gY, &dr2, nullptr, nullptr, lp2, accumulate, M, D, stream), "norm2 bwd");
     const unsigned char* dO2 = tr ? gY : gZ;
+    const unsigned char* dAo = tr ? gY1 : gZ1;
+    const iq_wgrad_problem_t wg[4] = {
+        {dO2, D, ws + a.hid, F, G + o.w2, G + o.b2, D, F},            // ffn.linear2
+        {gH, F, ws + a.x1, D, G + o.w1, G + o.b1, F, D},              // ffn.linear1
+        {dAo, D, ws + a.att, D, G + o.wo, G + o.bo, D, D},            // attention.w_concat
+        {gQKV, 3 * D, xin, D, G + o.wqkv, G + o.bqkv, 3 * D, D}};     // attention.w_q|w_k|w_v
+    // the LayerNorm gamma/beta partial rows of this layer ride on the same reduce launch
+    const int lrows = iq_ln_bwd_partial_rows(M, D);
+    const iq_reduce_seg_t lnseg[4] = {{lp2, lrows, 2L * D, G + o.g2, D}, {lp2 + D, lrows, 2L * D, G + o.be2, D},
+                                      {lp1, lrows, 2L * D, G + o.g1, D}, {lp1 + D, lrows, 2L * D, G + o.be1, D}};
+    auto one_wgrad = [&](int k, bool with_ln) {
+      return iq_gemm_bf16_wgrad_grouped(wg + k, 1, M, wws, w.wgrad_ws_bytes, accumulate, 0, with_ln ? lnseg : nullptr,
+                                        with_ln ? 4 : 0, stream);
+    };
     memset(&e, 0, sizeof(e));
     e.gate = ws + a.hid; e.ldg = F; e.gate_scale = dscale;
     iq_epilogue_t e2;
@@ -591,24 +610,17 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
              "ffn dgrad chain");
     } else {
       IQ_TRY(iq_gemm_bf16_nt(dO2, D, m->sht(o.t_w2), D, gH, F, M, F, D, &e, stream), "ffn2 dgrad");
+      if (ungrouped) IQ_TRY(one_wgrad(0, false), "ffn2 wgrad");
       IQ_TRY(iq_gemm_bf16_nt(gH, F, m->sht(o.t_w1), F, ws + w.gB, D, M, D, F, &e2, stream), "ffn1 dgrad");
+      if (ungrouped) IQ_TRY(one_wgrad(1, false), "ffn1 wgrad");
     }
     // norm1 backward (+ dropout1 mask)
     const iq_dropout_t dr1 = m->bwd_site(1 + 3 * l, step_dev, tr);
     IQ_TRY(iq_ln_bwd(ws + w.gB, ws + a.z1, (const float*)(ws + a.mean1), (const float*)(ws + a.rstd1), P + o.g1,
                      gZ1, gY1, &dr1, nullptr, nullptr, lp1, accumulate, M, D, stream), "norm1 bwd");
-    const unsigned char* dAo = tr ? gY1 : gZ1;
     IQ_TRY(iq_gemm_bf16_nt(dAo, D, m->sht(o.t_wo), D, ws + w.gAtt, D, M, D, D, nullptr, stream), "out-proj dgrad");
+    if (ungrouped) IQ_TRY(one_wgrad(2, false), "out-proj wgrad");
     IQ_TRY(iq_attn_bwd(ws + a.qkv, ws + a.att, ws + w.gAtt, (const float*)(ws + a.lse), gQKV, B, S, H, m->dh, stream), "attention bwd");
-    const iq_wgrad_problem_t wg[4] = {
-        {dO2, D, ws + a.hid, F, G + o.w2, G + o.b2, D, F},            // ffn.linear2
-        {gH, F, ws + a.x1, D, G + o.w1, G + o.b1, F, D},              // ffn.linear1
-        {dAo, D, ws + a.att, D, G + o.wo, G + o.bo, D, D},            // attention.w_concat
-        {gQKV, 3 * D, xin, D, G + o.wqkv, G + o.bqkv, 3 * D, D}};     // attention.w_q|w_k|w_v
-    // the LayerNorm gamma/beta partial rows of this layer ride on the same reduce launch
-    const int lrows = iq_ln_bwd_partial_rows(M, D);
-    const iq_reduce_seg_t lnseg[4] = {{lp2, lrows, 2L * D, G + o.g2, D}, {lp2 + D, lrows, 2L * D, G + o.be2, D},
-                                      {lp1, lrows, 2L * D, G + o.g1, D}, {lp1 + D, lrows, 2L * D, G + o.be1, D}};
     if (budget > 0) {
       (void)hipEventRecord(m->ev_ready[par], st);
       (void)hipStreamWaitEvent(m->side, m->ev_ready[par], 0);
@@ -620,7 +632,8 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
     memset(&e, 0, sizeof(e));
     e.residual = gZ1; e.ldr = D;
     IQ_TRY(iq_gemm_bf16_nt(gQKV, 3 * D, m->sht(o.t_wqkv), 3 * D, ws + w.gA, D, M, D, 3 * D, &e, stream), "qkv dgrad");
-    if (budget <= 0)
+    if (ungrouped) IQ_TRY(one_wgrad(3, true), "qkv wgrad");
+    else if (budget <= 0)
       IQ_TRY(iq_gemm_bf16_wgrad_grouped(wg, 4, M, wws, w.wgrad_ws_bytes, accumulate, 0, lnseg, 4, stream), "layer weight gradients");
   }
   for (int par = 0; par < 2; ++par)
