@@ -229,12 +229,12 @@ def test_gemm_chain_equals_two_gemms(L, M, D, F):
     close_bf16(Y, ref, "chain vs fp64")
 
 
-@pytest.mark.parametrize("M,K", [(5000, 768), (130, 576), (50432, 768), (999, 384)])
-def test_gemm_residual_as_k_stages(L, M, K):
+@pytest.mark.parametrize("M,K,N_", [(5000, 768, 192), (130, 576, 192), (50432, 768, 192), (999, 384, 192), (4000, 1024, 128),
+                                    (700, 384, 128)])
+def test_gemm_residual_as_k_stages(L, M, K, N_):
     """C = A W^T + R with N = 192 and nothing else in the tail takes the 192-column tile with the residual streamed as
     extra K stages against identity fragments: must be bit-identical to the ordinary epilogue path (forced here by a
     zero bias, which disables the shortcut) and match fp64."""
-    N_ = 192
     g = torch.Generator(device="cuda").manual_seed(M + K)
     A = bf(torch.randn(M, K, device=dev(), generator=g))
     B = bf(torch.randn(N_, K, device=dev(), generator=g) / math.sqrt(K))

@@ -369,12 +369,13 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   // C = A W^T + R, nothing else in the tail, whole rows in one 192-column tile: residual streamed as extra K stages.
   // (the plain 192-column tile reads A once -- N=192 K=768: 27.6 vs 37.3 us -- but lost it all to an exposed residual fetch)
   static const bool no_resk = getenv("IQ_GEMM_NO_RESK") != nullptr;
-  if (!no_resk && async_ok && epi_mode == EPI_RES && N == 192 && K >= 384 && !p.bias && !p.relu && !p.drop_on &&
+  if (!no_resk && async_ok && epi_mode == EPI_RES && (N == 192 || N == 128) && K >= 384 && !p.bias && !p.relu && !p.drop_on &&
       ((uintptr_t)p.residual % 16) == 0) {
     p.tiles_m = (M + BM - 1) / BM;
     p.tiles_n = 1;
-    const size_t lds = (size_t)3 * (BM + 192) * 32 * 2;     // 60 KiB: under the 64 KiB default cap, no attribute call
-    gemm_nt_async_kernel<128, 192, EPI_RES, true><<<p.tiles_m, GEMM_THREADS, lds, st>>>(p);
+    const size_t lds = (size_t)3 * (BM + N) * 32 * 2;       // <= 60 KiB: under the 64 KiB default cap, no attribute call
+    if (N == 192) gemm_nt_async_kernel<128, 192, EPI_RES, true><<<p.tiles_m, GEMM_THREADS, lds, st>>>(p);
+    else gemm_nt_async_kernel<128, 128, EPI_RES, true><<<p.tiles_m, GEMM_THREADS, lds, st>>>(p);
     return iq_launch_status();
   }
   // The weight-stationary persistent kernel (gemm_ws.hip) is correct but measured 5-25 % SLOWER than the tiled
