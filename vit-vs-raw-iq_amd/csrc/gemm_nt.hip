@@ -305,7 +305,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
   IQ_STAMP(3);
   gemm_epilogue<MT, NT, RESK ? (EPI & ~EPI_RES) : EPI>(p, acc, m0 + (wave >> 1) * (BMT / 2), n0 + (wave & 1) * (BN / 2), lane);
   IQ_STAMP(4);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef IQ_GEMM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // only to time the store drain: a wave may retire with stores in flight
+#endif
   IQ_STAMP(5);
 }
 
