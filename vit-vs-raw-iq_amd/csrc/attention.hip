@@ -171,12 +171,12 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16* __res
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int key = k0 + kb + kt * 16 + 4 * g + r;
-                float x = sc[u][kt][r] * scale_log2;
-                x = key < S ? x : NEG_BIG;
+                float x = sc[u][kt][r];               // raw score: the positive scale commutes with max and is folded
+                x = key < S ? x : NEG_BIG;            // into the exp2 argument below (one fma instead of mul + sub)
                 sc[u][kt][r] = x;
                 mx = fmaxf(mx, x);
               }
-            mx = group4_max(mx);
+            mx = group4_max(mx) * scale_log2;         // running max m[u] lives in the scaled (log2) domain
             const float mn = fmaxf(m[u], mx);
             const float alpha = fast_exp2(m[u] - mn);
             m[u] = mn;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16* __res
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const float pv = fast_exp2(sc[u][kt][r] - mn);
+                const float pv = fast_exp2(fmaf(sc[u][kt][r], scale_log2, -mn));
                 sc[u][kt][r] = pv;
                 rs += pv;
               }
