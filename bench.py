@@ -3,18 +3,24 @@
 gradient all-reduce + clip + AdamW) on synthetic frames already resident in HBM.
 
   python bench.py --gpus N --steps K --warmup W [--config B|C|Cp|D|A|ref] [--batch per-GPU]
-  N>1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+N > 1 without a launcher: bench.py starts its own N ranks (one process per GPU, RCCL) BEFORE touching the GPU and
+exits non-zero unless all N joined.  Under `python -m torch.distributed.run ... bench.py --gpus N` it reads
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment instead.
 
 Default workload = BASELINE.json configs[1]: ViT-Tiny/16 on 224x224 single-channel frames, 19 classes,
 256 frames per GPU, dropout 0.1 ON, bf16 activations / fp32 master weights.  Weak scaling: per-GPU batch fixed.
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
   roofline     -- dominant kernel family, timed live with HIP event pairs on the launch stream
                   (iq_prof_* in include/iqvit.h) over profiled steps of the same workload
   cpu_baseline -- the CPU oracle (oracle/iq_oracle.py, "port") timed on this host's cores on a bounded sample
+  step         -- whole-step fractions of the SURVEY 8(d) roofline: frames/s x algorithmic bytes (flops) per frame
+  secondary    -- the raw-IQ transformer (BASELINE.json configs[2]) measured the same way in the same run
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,9 +28,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
-
-import torch
-import torch.distributed as dist
 
 CONFIGS = {
     # name: (kind, ctor kwargs, per-GPU batch, drop_prob, weight_decay, description)
@@ -50,6 +53,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16
 RIDGE = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
 FAMILIES = ["gemm_nt", "wgrad", "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd", "misc", "optimizer"]
+PROFILE_ROUND = "r02"        # profiles/<round>_pmc_family_cfg<id>.json holds the PMC passes of this round's kernels
 
 
 def geometry(kind, kw):
@@ -58,26 +62,36 @@ def geometry(kind, kw):
         tok = (kw["img_size_h"] // kw["patch_size"]) * (kw["img_size_w"] // kw["patch_size"])
         P = kw["in_channels"] * kw["patch_size"] ** 2
         S = tok + 1
+        in_elems = kw["in_channels"] * kw["img_size_h"] * kw["img_size_w"]
     else:
         k = 1 if kw["embedding_type"] == "conv1d" else kw["segment_size"]
         tok = kw["seq_length"] // k
         P = kw["in_channels"] * k
         S = tok + (1 if kw["use_cls_token"] else 0)
-    return dict(D=D, F=F, L=L, H=H, dh=D // H, tok=tok, P=P, Ppad=(P + 31) // 32 * 32, S=S, K=kw["num_classes"])
+        in_elems = kw["in_channels"] * kw["seq_length"]
+    return dict(D=D, F=F, L=L, H=H, dh=D // H, tok=tok, P=P, Ppad=(P + 31) // 32 * 32, S=S, K=kw["num_classes"],
+                in_elems=in_elems)
 
 
-def family_work(g, B, training_dropout):
+def param_count(g):
+    D, F, L, K, P = g["D"], g["F"], g["L"], g["K"], g["P"]
+    per_layer = 4 * (D * D + D) + 2 * D * F + F + D + 4 * D
+    return D * P + D + D + L * per_layer + D * K + K
+
+
+def family_work(g, B, training_dropout, fused_ln):
     """Algorithmic bytes / flops per training step and launches per step for each kernel family
     (DESIGN.md section 'Kernels and rooflines' derives the same numbers)."""
     D, F, L, H, dh, S, tok, Ppad = g["D"], g["F"], g["L"], g["H"], g["dh"], g["S"], g["tok"], g["Ppad"]
     M, MT = B * S, B * tok
-    nt = []   # (M, N, K, extra_MN_reads)
-    nt.append((MT, D, Ppad, 0))                 # embedding
+    nt = []   # (M, N, K, extra_MN_reads, extra_MN_writes)
+    nt.append((MT, D, Ppad, 0, 0))                 # embedding
+    ln_out = 1 if fused_ln else 0                  # out-proj / ffn2 also write the LayerNorm output when fused
     for _ in range(L):
-        nt += [(M, 3 * D, D, 0), (M, D, D, 1), (M, F, D, 0), (M, D, F, 1)]            # fwd: qkv, out(+res), ffn1, ffn2(+res)
-        nt += [(M, F, D, 1), (M, D, F, 1), (M, D, D, 0), (M, D, 3 * D, 1)]            # dgrad: ffn2(+gate), ffn1(+res), out, qkv(+res)
-    b_nt = sum(2 * (m * k + n * k + m * n) + 2 * m * n * ex for m, n, k, ex in nt)
-    f_nt = sum(2 * m * n * k for m, n, k, ex in nt)
+        nt += [(M, 3 * D, D, 0, 0), (M, D, D, 1, ln_out), (M, F, D, 0, 0), (M, D, F, 1, ln_out)]   # fwd: qkv, out(+res), ffn1, ffn2(+res)
+        nt += [(M, F, D, 1, 0), (M, D, F, 1, 0), (M, D, D, 0, 0), (M, D, 3 * D, 1, 0)]             # dgrad: ffn2(+gate), ffn1(+res), out, qkv(+res)
+    b_nt = sum(2 * (m * k + n * k + m * n) + 2 * m * n * (ex + wx) for m, n, k, ex, wx in nt)
+    f_nt = sum(2 * m * n * k for m, n, k, ex, wx in nt)
     wg = [(MT, D, Ppad)]
     for _ in range(L):
         wg += [(M, D, F), (M, F, D), (M, D, D), (M, 3 * D, D)]
@@ -87,14 +101,14 @@ def family_work(g, B, training_dropout):
     f_af = L * 4 * B * H * S * S * dh
     b_ab = L * (2 * M * 3 * D * 2 + 2 * M * D * 2 + 4 * B * H * S)
     f_ab = L * 14 * B * H * S * S * dh          # 7 MFMA products (S and dP are computed in both phases)
-    b_lf = 2 * L * (2 * M * D * 2 + 8 * M)
+    b_lf = 0 if fused_ln else 2 * L * (2 * M * D * 2 + 8 * M)
     b_lb = 2 * L * (2 * M * D * (3 + (1 if training_dropout else 0)) + 8 * M)
     return {
         "gemm_nt": dict(bytes=b_nt, flops=f_nt, launches=len(nt)),
         "wgrad": dict(bytes=b_wg, flops=f_wg, launches=len(wg)),
         "attn_fwd": dict(bytes=b_af, flops=f_af, launches=L),
         "attn_bwd": dict(bytes=b_ab, flops=f_ab, launches=L),
-        "ln_fwd": dict(bytes=b_lf, flops=0, launches=2 * L),
+        "ln_fwd": dict(bytes=b_lf, flops=0, launches=0 if fused_ln else 2 * L),
         "ln_bwd": dict(bytes=b_lb, flops=0, launches=2 * L),
     }
 
@@ -105,8 +119,18 @@ def train_flops_per_frame(g):
     return 3 * fwd
 
 
+def algorithmic_bytes_per_frame(g, B):
+    """input read + 2 x saved activations (written forward, read backward; the flash-style minimum
+    L*(8*S*D + S*F) bf16 elements + L*H*S fp32 log-sum-exp) + 3 x parameter bytes / per-GPU batch.
+    cfg B: 22.1 MB, cfg C: 3.3 MB, cfg D: 90 MB per frame."""
+    D, F, L, H, S = g["D"], g["F"], g["L"], g["H"], g["S"]
+    saved = L * (8 * S * D + S * F) * 2 + L * H * S * 4
+    return g["in_elems"] * 2 + 2 * saved + 3 * 4 * param_count(g) / B
+
+
 def cpu_baseline(kind, kw, drop, wd, budget_s=20.0):
     """The CPU oracle's full training step (dropout ON, clip, AdamW) on this host, bounded sample."""
+    import torch
     import iq_oracle as O
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(max(1, min(ncpu, 16)))   # a 1-GPU box owns 16 host cores; more threads oversubscribe (measured)
@@ -131,51 +155,53 @@ def cpu_baseline(kind, kw, drop, wd, budget_s=20.0):
             "sample": f"{n} full training steps of batch {b} (same model/config, fp32, dropout on) after 1 warm-up, {el:.1f} s"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="B", choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
-    ap.add_argument("--graph", type=int, default=-1, help="hipGraph replay of the step (default: on for 1 GPU)")
-    ap.add_argument("--buckets", type=int, default=4)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--prof-steps", type=int, default=5)
-    ap.add_argument("--drop", type=float, default=-1.0, help="override the config's dropout probability (diagnostics)")
-    a = ap.parse_args()
+def self_launch(a, argv):
+    """`--gpus N` with no launcher: start N ranks (one per GPU) before this process has touched the GPU, relay
+    rank 0's JSON line, exit non-zero unless every rank finished."""
+    import socket
+    import torch
+    ndev = torch.cuda.device_count()          # does not initialise the GPU
+    backend = os.environ.get("IQ_DIST_BACKEND", "nccl")
+    if backend == "nccl" and ndev < a.gpus:
+        print(f"[bench] --gpus {a.gpus} needs {a.gpus} GPUs for {a.gpus} RCCL ranks, this node shows {ndev}", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), IQ_BENCH_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    if any(codes):
+        print(f"[bench] rank exit codes {codes}: fewer than {a.gpus} ranks completed", file=sys.stderr)
+        return 1
+    return 0
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)")
-    ndev = torch.cuda.device_count()
-    torch.cuda.set_device(local_rank % ndev)
-    dev = torch.device("cuda", local_rank % ndev)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("IQ_DIST_BACKEND", "nccl")     # "gloo" only to rehearse the N>1 path on a 1-GPU box
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-    if a.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
+def measure(a, config_id, dev, rank, world, steps, warmup, prof_steps, want_cpu):
+    """Timed steps + profiled leg (+ CPU baseline) for one named configuration -> dict of results (rank 0) or None."""
+    import ctypes
+    import torch
+    import torch.distributed as dist
     import vit_vs_raw_iq_amd as P
     from vit_vs_raw_iq_amd.trainer import FusedTrainer
     import vit_vs_raw_iq_amd._native as N
 
-    kind, kw, batch, drop, wd, desc = CONFIGS[a.config]
+    kind, kw, batch, drop, wd, desc = CONFIGS[config_id]
     B = a.batch or batch
     if a.drop >= 0:
         drop = a.drop
-    torch.manual_seed(0)                       # identical init on every rank (verified seed-deterministic)
+    torch.manual_seed(0)                       # identical init on every rank; FusedTrainer also broadcasts rank 0's
     cls = P.AMCTransformerViT if kind == "vit" else P.AMCTransformerRawIQ
     model = cls(drop_prob=drop, device="cuda", **kw).to(dev).train()
-    use_graph = (world == 1) if a.graph < 0 else bool(a.graph)
+    use_graph = True if a.graph < 0 else bool(a.graph)
     tr = FusedTrainer(model, lr=1e-4, weight_decay=wd, betas=(0.9, 0.99), label_smoothing=0.1, max_norm=1.0,
                       n_buckets=a.buckets, use_graph=use_graph, dropout_seed=1234)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
@@ -188,11 +214,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(a.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         tr.step(x, y)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         tr.step(x, y)
     barrier()
     el = time.perf_counter() - t0
@@ -201,7 +227,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     loss, acc, _ = tr.read_stats()
-    frames = B * world * a.steps
+    frames = B * world * steps
     value = frames / el
 
     geo = geometry(kind, kw)
@@ -211,30 +237,31 @@ def main():
         # only rank 0 times its kernels
         if rank != 0:
             tr.use_graph = False
-            for _ in range(1 + a.prof_steps):
+            for _ in range(1 + prof_steps):
                 tr.step(x, y)
             torch.cuda.synchronize()
     if rank == 0 and not a.no_roofline:
         # profiled leg: same workload, eager launches, HIP event pair around every kernel-family call
         L = N.lib()
         tr.use_graph = False
-        ms = (__import__("ctypes").c_double * 8)()
-        cnt = (__import__("ctypes").c_longlong * 8)()
+        ms = (ctypes.c_double * 8)()
+        cnt = (ctypes.c_longlong * 8)()
         tr.step(x, y)
         torch.cuda.synchronize()
         L.iq_prof_enable(1)
         L.iq_prof_collect(ms, cnt)
-        for _ in range(a.prof_steps):
+        for _ in range(prof_steps):
             tr.step(x, y)
         L.iq_prof_collect(ms, cnt)
         L.iq_prof_enable(0)
-        per_step = {f: ms[i] / a.prof_steps for i, f in enumerate(FAMILIES)}
-        work = family_work(geo, B, drop > 0)
+        per_step = {f: ms[i] / prof_steps for i, f in enumerate(FAMILIES)}
+        fused_ln = int(cnt[FAMILIES.index("ln_fwd")]) == 0
+        work = family_work(geo, B, drop > 0, fused_ln)
         dom = max(work, key=lambda f: per_step[f])
         w = work[dom]
         dur_ms = per_step[dom]
         ai = w["flops"] / max(w["bytes"], 1)
-        launches = max(int(cnt[FAMILIES.index(dom)]) // a.prof_steps, 1)
+        launches = max(int(cnt[FAMILIES.index(dom)]) // prof_steps, 1)
         if ai > RIDGE:
             ach = w["flops"] / (dur_ms * 1e-3) / 1e12
             roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -245,14 +272,16 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
         # HBM bytes per launch from the PMC counters cannot be collected inside this process (rocprofv3 --pmc passes,
         # scripts/pmc_family.sh); report the committed measurement of the same workload when there is one.
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_pmc_family_cfg{a.config}.json")
-        if os.path.exists(pmc_path) and a.batch in (0, CONFIGS[a.config][2]) and a.drop < 0 and world == 1:
+        pmc_path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_family_cfg{config_id}.json")
+        if os.path.exists(pmc_path) and a.batch in (0, batch) and a.drop < 0 and world == 1:
             try:
                 with open(pmc_path) as fh:
                     pmc = json.load(fh)
                 if dom in pmc:
                     roof["traffic"] = int(pmc[dom]["hbm_bytes_per_launch"])
-                    roof["traffic_source"] = os.path.relpath(pmc_path, os.path.dirname(os.path.abspath(__file__)))
+                    roof["traffic_source"] = os.path.relpath(pmc_path, ROOT)
+                if "mfma_util" in pmc:
+                    roof["mfma_util_step"] = pmc["mfma_util"]       # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x SIMDs)
             except (OSError, ValueError, KeyError):
                 pass
         roof["avg_launch_us"] = round(dur_ms * 1e3 / launches, 2)
@@ -260,33 +289,105 @@ def main():
         roof["algorithmic_bytes_per_launch"] = int(w["bytes"] / launches)
         roof["family_ms_per_step"] = {f: round(v, 4) for f, v in per_step.items()}
         tot = sum(per_step.values())
-        print(f"[bench] kernel time per step by family (HIP events, eager): "
+        print(f"[bench:{config_id}] kernel time per step by family (HIP events, eager): "
               + ", ".join(f"{f} {v:.3f} ms" for f, v in per_step.items()) + f"; sum {tot:.3f} ms", file=sys.stderr)
         for f, wk in work.items():
             d = per_step[f] * 1e-3
-            if d > 0:
-                print(f"[bench]   {f:9s} {wk['bytes'] / d / 1e9:8.1f} GB/s algorithmic  {wk['flops'] / d / 1e12:7.2f} TFLOP/s"
+            if d > 0 and wk["launches"]:
+                print(f"[bench:{config_id}]   {f:9s} {wk['bytes'] / d / 1e9:8.1f} GB/s algorithmic  {wk['flops'] / d / 1e12:7.2f} TFLOP/s"
                       f"  ({wk['launches']} launches/step)", file=sys.stderr)
 
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(kind, kw, drop, wd)
+    if rank == 0 and want_cpu:
+        cpu = cpu_baseline(kind, kw, drop, wd, budget_s=a.cpu_budget)
+    del tr, model
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    fl = train_flops_per_frame(geo)
+    by = algorithmic_bytes_per_frame(geo, B)
+    return {
+        "value": round(value, 1), "ms_per_step": round(el / steps * 1e3, 3),
+        "config": {"workload": desc, "config_id": config_id, "per_gpu_batch": B, "global_batch": B * world,
+                   "tokens_per_frame": geo["S"], "parallelism": f"dp{world}", "dropout": drop,
+                   "hipgraph": bool(use_graph), "train_gflop_per_frame": round(fl / 1e9, 4),
+                   "algorithmic_mb_per_frame": round(by / 1e6, 3)},
+        "step": {"model_tflops": round(value * fl / 1e12, 2),
+                 "step_mfma_frac": round(value * fl / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
+                 "step_hbm_gbs": round(value * by / 1e9, 1),
+                 "step_hbm_frac": round(value * by / 1e9 / (HBM_PEAK_GBS * world), 4)},
+        "final_loss": round(loss, 4), "train_acc": round(acc, 4), "roofline": roof, "cpu_baseline": cpu,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="B", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--graph", type=int, default=-1, help="hipGraph replay of the step (default: on)")
+    ap.add_argument("--buckets", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the raw-IQ (cfg C) measurement beside cfg B")
+    ap.add_argument("--prof-steps", type=int, default=5)
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-oracle work per configuration")
+    ap.add_argument("--drop", type=float, default=-1.0, help="override the config's dropout probability (diagnostics)")
+    a = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        sys.exit(self_launch(a, sys.argv[1:]))
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        print(f"[bench] --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a "
+              f"{world}-GPU number as a {a.gpus}-GPU one", file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)")
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
+    backend = "none"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("IQ_DIST_BACKEND", "nccl")     # "gloo" only to rehearse the N>1 path on a 1-GPU box
+        if backend == "nccl":
+            if ndev < world:
+                raise SystemExit(f"{world} RCCL ranks need {world} GPUs, {ndev} visible")
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        assert dist.get_world_size() == world
+
+    main_res = measure(a, a.config, dev, rank, world, a.steps, a.warmup, a.prof_steps,
+                       want_cpu=(world == 1 and not a.no_cpu_baseline))
+    second = None
+    if a.config == "B" and not a.no_secondary and a.batch == 0:
+        second = measure(a, "C", dev, rank, world, a.steps, a.warmup, a.prof_steps,
+                         want_cpu=(world == 1 and not a.no_cpu_baseline))
 
     if rank == 0:
-        fl = train_flops_per_frame(geo)
         out = {
-            "metric": "IQ frames/sec training (fwd+loss+bwd+clip+AdamW)", "value": round(value, 1), "unit": "frames/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3),
+            "metric": "IQ frames/sec training (fwd+loss+bwd+clip+AdamW)", "value": main_res["value"], "unit": "frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": desc, "config_id": a.config, "per_gpu_batch": B, "global_batch": B * world,
-                       "tokens_per_frame": geo["S"], "parallelism": f"dp{world}", "dropout": drop,
-                       "hipgraph": bool(use_graph), "train_gflop_per_frame": round(fl / 1e9, 4),
-                       "model_tflops": round(value * fl / 1e12, 2),
-                       "mfma_frac_of_dense_bf16_peak": round(value * fl / 1e12 / (MFMA_PEAK_TFLOPS * world), 4)},
-            "final_loss": round(loss, 4), "train_acc": round(acc, 4),
-            "roofline": roof, "cpu_baseline": cpu,
+            "config": main_res["config"], "step": main_res["step"], "final_loss": main_res["final_loss"],
+            "train_acc": main_res["train_acc"],
+            "dist": {"backend": backend, "rccl_ranks": world if backend == "nccl" else 0, "ranks": world},
+            "roofline": main_res["roofline"], "cpu_baseline": main_res["cpu_baseline"],
         }
+        if second is not None:
+            out["secondary"] = {"metric": out["metric"], "unit": "frames/s", **second}
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

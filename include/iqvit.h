@@ -25,7 +25,7 @@ typedef void* iq_stream_t; /* hipStream_t */
 
 enum { IQ_STATUS_OK = 0, IQ_STATUS_ARG = 1, IQ_STATUS_UNSUPPORTED = 2, IQ_STATUS_LAUNCH = 3 };
 
-/* Dropout site: Philox4x32-10 keyed by seed, counter (element_index/8, site, step).
+/* Dropout site: Philox4x32-7 (7 rounds: csrc/common.h) keyed by seed, counter (element_index/8, site, step).
  * p == 0 disables.  Masks are regenerated in backward from the same triple, never stored. */
 typedef struct iq_dropout {
   uint64_t seed;
@@ -132,11 +132,20 @@ int iq_gemm_bf16_wgrad_grouped(const iq_wgrad_problem_t* probs, int nprob, int M
  * (V/models/layers/multi_head_attention.py:34-47): reads the packed projection output
  * qkv[B*S, 3*D] (q | k | v, head h at columns h*dh) and writes out[B*S, D] already "concatenated".
  * The S x S scores never reach HBM; lse[B,H,S] (fp32, natural log) is kept for backward.
- * dh in {16,32,64}. */
+ * dh in {16,32,64}; S <= 4096 (backward keeps the staged side in LDS in chunks when one image does not fit:
+ * embedding_type='conv1d', S = 1025, R/models/encoder.py:34-41). */
 int iq_attn_supported(int S, int dh);
 int iq_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int dh, iq_stream_t stream);
 int iq_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int S, int H,
                 int dh, iq_stream_t stream);
+/* The optional mask branch, V/models/layers/scale_dot_product_attention.py:30-31 (`score.masked_fill(mask == 0, -10000)`
+ * after the 1/sqrt(dh) scaling; no reference caller passes a mask).  mask: uint8 (B, 1 | H, S, S), 0 = masked;
+ * mask_hstride = S*S when the mask has a head dimension, 0 when it is shared by all heads.  mask NULL = the calls above.
+ * Backward passes no gradient through masked positions (masked_fill). */
+int iq_attn_fwd_masked(const void* qkv, void* out, float* lse, const uint8_t* mask, long mask_hstride, int B, int S,
+                       int H, int dh, iq_stream_t stream);
+int iq_attn_bwd_masked(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                       const uint8_t* mask, long mask_hstride, int B, int S, int H, int dh, iq_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Embedding front end.  iq_patchify turns the fp32 input frame batch into the bf16 GEMM
@@ -166,7 +175,8 @@ int iq_embed_bwd_gather(const void* dx0, void* demb, float* dcls, int B, int S, 
  * R/models/transformer_rawIQ.py:67-70,88-96); logits = feat*W^T + b (V/models/amc_transformer.py:29-30).
  * featn [B,D] fp32 (the pooled feature, normalised but pre-affine when LN is on) and hstat [B,2]
  * (mean, rstd) are kept for backward.
- * iq_ce_fwd_bwd: CrossEntropyLoss(label_smoothing) mean over `denom` frames (global batch under DDP),
+ * iq_ce_fwd_bwd: CrossEntropyLoss(label_smoothing) mean over `denom` frames (global batch under DDP); a label
+ * outside [0, K) makes that frame's loss and gradient NaN (torch asserts on the device),
  * V/training/train.py:405; writes loss_sum (sum over local frames of per-frame loss), n_correct
  * (argmax==label, V/training/train.py:205-207) and dlogits.  Pass dlogits NULL to skip the gradient.
  * iq_head_bwd: gradients of W,b,(ln gamma,beta) and d(x_L) (bf16 [B*S,D], zero outside the pooled rows). */
@@ -222,6 +232,11 @@ size_t iq_model_shadow_bytes(const iq_model_t* m);
 size_t iq_model_workspace_bytes(const iq_model_t* m, int batch, int training);
 /* bind device buffers (caller-owned, must outlive use): params/grads flat fp32, pe fp32 [S,D], shadow bytes */
 int iq_model_bind(iq_model_t* m, float* params, float* grads, const float* pe, void* shadow);
+/* Optional: a caller-owned persistent DEVICE u32 that holds the dropout step.  When bound, iq_model_forward with
+ * step == 0xFFFFFFFF increments it on the device (hipGraph replays then draw fresh masks), any other step value is
+ * written into it; backward regenerates masks from it.  Unbound, a slot of the workspace is used (uninitialised
+ * after every workspace reallocation: bind a counter for reproducible masks under graph replay). */
+int iq_model_bind_step_counter(iq_model_t* m, uint32_t* counter);
 int iq_model_refresh_shadow(iq_model_t* m, iq_stream_t stream);
 /* same, minus the flat fp32->bf16 mirror (iq_adamw_step has just written it) */
 int iq_model_refresh_transposed(iq_model_t* m, iq_stream_t stream);

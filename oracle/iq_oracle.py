@@ -178,10 +178,13 @@ def custom_layer_norm(x, gamma, beta, eps=1e-12):
     return gamma * ((x - mean) / torch.sqrt(var + eps)) + beta
 
 
-def attention_core(q, k, v):
-    """q,k,v: (B,H,S,dh).  softmax(q k^T / sqrt(dh)) v; no mask, no dropout."""
+def attention_core(q, k, v, mask=None):
+    """q,k,v: (B,H,S,dh).  softmax(q k^T / sqrt(dh)) v; no dropout.  Optional mask: positions with mask == 0 get the
+    score -10000 after scaling (scale_dot_product_attention.py:26-31; no reference caller passes one)."""
     dh = q.shape[-1]
     score = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(dh)
+    if mask is not None:
+        score = score.masked_fill(mask == 0, -10000)
     score = score - score.max(dim=-1, keepdim=True).values
     e = torch.exp(score)
     prob = e / e.sum(dim=-1, keepdim=True)
@@ -220,24 +223,39 @@ def encoder_forward(cfg: OracleConfig, sd: State, src, train=False):
         raise ValueError(
             f"Sequence length {S} exceeds maximum length {pe.shape[0]}. Increase max_len parameter.")
     x = _dropout(x + pe[:S].unsqueeze(0), p, train)
-    H = cfg.n_head
-    dh = cfg.d_model // H
     for i in range(cfg.n_layers):
-        pre = f"encoder.layers.{i}."
-
-        def lin(t, name):
-            return t @ sd[pre + name + ".weight"].t() + sd[pre + name + ".bias"]
-
-        q = lin(x, "attention.w_q").view(B, S, H, dh).transpose(1, 2)
-        k = lin(x, "attention.w_k").view(B, S, H, dh).transpose(1, 2)
-        v = lin(x, "attention.w_v").view(B, S, H, dh).transpose(1, 2)
-        a = attention_core(q, k, v).transpose(1, 2).reshape(B, S, cfg.d_model)
-        a = lin(a, "attention.w_concat")
-        x = custom_layer_norm(_dropout(a, p, train) + x, sd[pre + "norm1.gamma"], sd[pre + "norm1.beta"])
-        h = _dropout(torch.relu(lin(x, "ffn.linear1")), p, train)
-        h = lin(h, "ffn.linear2")
-        x = custom_layer_norm(_dropout(h, p, train) + x, sd[pre + "norm2.gamma"], sd[pre + "norm2.beta"])
+        x = encoder_layer(sd, f"encoder.layers.{i}.", x, cfg.n_head, p, train)
     return x
+
+
+def multi_head_attention(sd: State, pre: str, x, n_head: int, mask=None):
+    """MultiHeadAttention.forward(q=x, k=x, v=x) (multi_head_attention.py:16-32); `pre` = state_dict prefix of the module."""
+    B, S, D = x.shape
+    dh = D // n_head
+
+    def lin(t, name):
+        return t @ sd[pre + name + ".weight"].t() + sd[pre + name + ".bias"]
+
+    q = lin(x, "w_q").view(B, S, n_head, dh).transpose(1, 2)
+    k = lin(x, "w_k").view(B, S, n_head, dh).transpose(1, 2)
+    v = lin(x, "w_v").view(B, S, n_head, dh).transpose(1, 2)
+    a = attention_core(q, k, v, mask).transpose(1, 2).reshape(B, S, D)
+    return lin(a, "w_concat")
+
+
+def feed_forward(sd: State, pre: str, x, p=0.0, train=False):
+    """PositionwiseFeedForward.forward (position_wise_feed_forward.py:12-17)."""
+    h = torch.relu(x @ sd[pre + "linear1.weight"].t() + sd[pre + "linear1.bias"])
+    h = _dropout(h, p, train)
+    return h @ sd[pre + "linear2.weight"].t() + sd[pre + "linear2.bias"]
+
+
+def encoder_layer(sd: State, pre: str, x, n_head: int, p=0.0, train=False, mask=None):
+    """EncoderLayer.forward, post-norm (encoder_layer.py:18-35)."""
+    a = multi_head_attention(sd, pre + "attention.", x, n_head, mask)
+    x = custom_layer_norm(_dropout(a, p, train) + x, sd[pre + "norm1.gamma"], sd[pre + "norm1.beta"])
+    h = feed_forward(sd, pre + "ffn.", x, p, train)
+    return custom_layer_norm(_dropout(h, p, train) + x, sd[pre + "norm2.gamma"], sd[pre + "norm2.beta"])
 
 
 def model_forward(cfg: OracleConfig, sd: State, src, train=False):

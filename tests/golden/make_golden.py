@@ -58,6 +58,20 @@ CASES = {
     # mean pooling head (use_cls_token=False)
     "rawiq_nocls": ("rawiq", dict(in_channels=2, seq_length=512, num_classes=5, d_model=64, n_head=4, n_layers=1,
                                   ffn_hidden=128, use_cls_token=False, embedding_type="segment", segment_size=32), 3, False),
+    # ---- full-depth cases of the benchmarked configurations (weights regenerated from the seed by the build's own
+    #      init, whose bit-equality to the reference's is asserted below) ----------------------------
+    # configs[1] ViT-Tiny/16 224x224 at its full depth of 12
+    "vit_tiny224_L12": ("vit", dict(in_channels=1, img_size_h=224, img_size_w=224, patch_size=16, num_classes=19,
+                                    d_model=192, n_head=3, n_layers=12, ffn_hidden=768), 2, False),
+    # configs[3] ViT-Base/16 geometry (D768 / H12 / F3072), 2-layer truncation (341 MB of fp32 weights at L12)
+    "vit_base_L2": ("vit", dict(in_channels=1, img_size_h=224, img_size_w=224, patch_size=16, num_classes=19,
+                                d_model=768, n_head=12, n_layers=2, ffn_hidden=3072), 2, False),
+    # configs[2] rawIQ train.py defaults at full depth 6
+    "rawiq_C_L6": ("rawiq", dict(in_channels=2, seq_length=1024, num_classes=19, d_model=128, n_head=8, n_layers=6,
+                                 ffn_hidden=1024, use_cls_token=True, embedding_type="segment", segment_size=16), 2, False),
+    # published best rawIQ geometry at full depth 9
+    "rawiq_Cp_L9": ("rawiq", dict(in_channels=2, seq_length=1024, num_classes=19, d_model=256, n_head=8, n_layers=9,
+                                  ffn_hidden=1024, use_cls_token=True, embedding_type="segment", segment_size=16), 2, False),
 }
 
 # parameter-count known answers (V/main.ipynb:694,758-773)
@@ -94,7 +108,7 @@ def digest(t):
     return hashlib.sha256(np.ascontiguousarray(t.detach().cpu().numpy()).tobytes()).hexdigest()[:16]
 
 
-def worker(tree):
+def worker(tree, only=None):
     import typing
     sys.dont_write_bytecode = True
     if not hasattr(typing, "LiteralString"):
@@ -122,7 +136,7 @@ def worker(tree):
     print(f"[{tree}] parameter counts OK: {[c[1] for c in counts]}")
 
     for name, (t, kw, B, full) in CASES.items():
-        if t != tree:
+        if t != tree or (only and name not in only):
             continue
         cfg = O.OracleConfig(kind=tree, drop_prob=0.0, **kw)
         # ---- init parity: same seed -> bit-identical parameters -------------------------
@@ -175,7 +189,8 @@ def worker(tree):
         gn_or = float(gn_or)
         assert torch.allclose(logits_or, logits_ref, atol=1e-5, rtol=1e-5), (name, (logits_or - logits_ref).abs().max())
         assert abs(float(loss_or) - float(loss_ref.detach())) < 1e-6, name
-        assert abs(gn_or - float(gn_ref)) < 1e-5 * max(1.0, float(gn_ref)), (gn_or, float(gn_ref))
+        # the oracle sums squares in fp64; torch's clip_grad_norm_ reduces in fp32 (3.4e-5 off at ViT-Base's 14 M elements)
+        assert abs(gn_or - float(gn_ref)) < 1e-4 * max(1.0, float(gn_ref)), (gn_or, float(gn_ref))
         worst = 0.0
         for k in grads_ref:
             d = (grads_or[k] - grads_ref[k]).abs().max().item()
@@ -208,23 +223,74 @@ def worker(tree):
         else:
             # a few gradients in full: embedding, first-layer q, last norm, head
             for k in keys:
+                if kw["d_model"] > 256 and k.endswith("weight") and "mlp_head" not in k:
+                    continue        # ViT-Base: keep the fixture small (norms of every gradient are stored above)
                 if ("projection" in k or k.endswith("layers.0.attention.w_q.weight") or "mlp_head" in k
                         or k.endswith("cls_token") or k.endswith(f"layers.{kw['n_layers']-1}.norm2.gamma")):
                     fx["g:" + k] = grads_ref[k].numpy()
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **fx)
-    np.savez_compressed(os.path.join(HERE, f"param_counts_{tree}.npz"),
-                        kwargs=np.array([repr(c[0]) for c in counts]), counts=np.array([c[1] for c in counts]))
+    if tree == "vit" and (not only or "sublayers" in only):
+        sublayer_pins(torch, O)
+    if not only:
+        np.savez_compressed(os.path.join(HERE, f"param_counts_{tree}.npz"),
+                            kwargs=np.array([repr(c[0]) for c in counts]), counts=np.array([c[1] for c in counts]))
+
+
+def sublayer_pins(torch, O):
+    """The reference's layer modules run on their own (the files are byte-identical in both trees): EncoderLayer with and
+    without a src_mask (V/models/blocks/encoder_layer.py:18-35 -> scale_dot_product_attention.py:30-31), MultiHeadAttention,
+    PositionwiseFeedForward, LayerNorm.  Asserts the oracle's layer functions equal them and writes sublayers.npz."""
+    from models.blocks.encoder_layer import EncoderLayer
+    D, F, H, B, S = 64, 128, 2, 2, 10
+    torch.manual_seed(SEED)
+    layer = EncoderLayer(d_model=D, ffn_hidden=F, n_head=H, drop_prob=0.0)
+    with torch.no_grad():                      # non-trivial affine parameters
+        for n in ("norm1", "norm2"):
+            getattr(layer, n).gamma.uniform_(0.5, 1.5)
+            getattr(layer, n).beta.uniform_(-0.5, 0.5)
+    layer.eval()
+    g = torch.Generator().manual_seed(SEED + 7)
+    x = torch.randn(B, S, D, generator=g)
+    mask = (torch.rand(B, 1, S, S, generator=g) > 0.3).to(torch.int64)
+    mask[:, :, 2, :] = 0                       # one fully masked query row
+    sd = {k: v.detach().clone() for k, v in layer.state_dict().items()}
+    with torch.no_grad():
+        out = layer(x, None)
+        out_m = layer(x, mask)
+        mha = layer.attention(q=x, k=x, v=x, mask=None)
+        mha_m = layer.attention(q=x, k=x, v=x, mask=mask)
+        ffn = layer.ffn(x)
+        ln = layer.norm1(x)
+        q = layer.attention.split(layer.attention.w_q(x))
+        k = layer.attention.split(layer.attention.w_k(x))
+        v = layer.attention.split(layer.attention.w_v(x))
+        core, score = layer.attention.attention(q, k, v, mask=mask)
+    checks = [(O.encoder_layer(sd, "", x, H), out), (O.encoder_layer(sd, "", x, H, mask=mask), out_m),
+              (O.multi_head_attention(sd, "attention.", x, H), mha), (O.multi_head_attention(sd, "attention.", x, H, mask), mha_m),
+              (O.feed_forward(sd, "ffn.", x), ffn), (O.custom_layer_norm(x, sd["norm1.gamma"], sd["norm1.beta"]), ln),
+              (O.attention_core(q, k, v, mask), core)]
+    for i, (a, b) in enumerate(checks):
+        assert torch.allclose(a, b, atol=2e-6, rtol=1e-5), (i, (a - b).abs().max())
+    fx = {"dims": np.array([D, F, H, B, S]), "x": x.numpy(), "mask": mask.numpy(), "out": out.numpy(), "out_masked": out_m.numpy(),
+          "mha": mha.numpy(), "mha_masked": mha_m.numpy(), "ffn": ffn.numpy(), "ln": ln.numpy(), "core_masked": core.numpy(),
+          "score_masked": score.numpy()}
+    for k_, v_ in sd.items():
+        fx["w:" + k_] = v_.numpy()
+    np.savez_compressed(os.path.join(HERE, "sublayers.npz"), **fx)
+    print("[vit] sublayers: oracle layer functions == reference EncoderLayer / MultiHeadAttention / FFN / LayerNorm (mask branch included)")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tree", choices=["vit", "rawiq"])
+    ap.add_argument("--only", default="", help="comma-separated case names (default: all; existing fixtures are kept)")
     a = ap.parse_args()
+    only = [n for n in a.only.split(",") if n]
     if a.tree:
-        worker(a.tree)
+        worker(a.tree, only)
         return
     for tree in ("vit", "rawiq"):
-        subprocess.check_call([sys.executable, os.path.abspath(__file__), "--tree", tree])
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "--tree", tree] + (["--only", a.only] if only else []))
     print("golden fixtures written to", HERE)
 
 

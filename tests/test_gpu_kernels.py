@@ -148,11 +148,9 @@ def test_gemm_plain_and_bias_relu(L, M, N_, K):
 
 
 @pytest.mark.parametrize("M,N_,K", [(16384, 576, 192), (16384 + 77, 768, 192), (20000, 512, 128), (50432, 768, 192)])
-def test_gemm_wave_private_wide_n(L, M, N_, K):
-    """Wide N, K <= 192, many rows -- the cfg B FFN1 / QKV / FFN2-dgrad shapes, also what the opt-in wave-private kernel
-    (gemm_wp.hip, IQ_GEMM_WP=1) serves: ragged M tail, strided A, bias+ReLU, gate, residual, and a dropout mask that
-    depends only on (seed, step, site, element index), not on M or on which kernel ran."""
-    import os
+def test_gemm_wide_n_many_rows(L, M, N_, K):
+    """Wide N, K <= 192, many rows -- the cfg B FFN1 / QKV / FFN2-dgrad shapes: ragged M tail, strided A, bias+ReLU,
+    gate, residual, and a dropout mask that depends only on (seed, step, site, element index), not on M."""
     g = torch.Generator(device="cuda").manual_seed(M + N_)
     Abig = bf(torch.randn(M, K + 8, device=dev(), generator=g))
     A = Abig[:, :K]
@@ -468,7 +466,9 @@ def attn_ref(qkv, Bf, S, H, dh):
 
 
 @pytest.mark.parametrize("S,H,dh,Bf", [(5, 8, 16, 3), (17, 2, 32, 2), (65, 8, 16, 4), (129, 8, 16, 2), (65, 8, 32, 2),
-                                       (197, 3, 64, 3), (33, 2, 64, 2), (1025, 8, 16, 1), (224, 1, 64, 1)])
+                                       (197, 3, 64, 3), (33, 2, 64, 2), (1025, 8, 16, 1), (224, 1, 64, 1),
+                                       # backward keeps the staged side in LDS in chunks (conv1d embedding, S = 1025)
+                                       (1025, 8, 32, 1), (1025, 4, 64, 1), (481, 2, 64, 1), (700, 2, 32, 2)])
 def test_attention_fwd_bwd(L, S, H, dh, Bf):
     N = _N()
     assert L.iq_attn_supported(S, dh) == 1
@@ -515,8 +515,46 @@ def test_attention_peaked_softmax_is_stable(L):
 def test_attention_limits(L):
     assert L.iq_attn_supported(197, 64) == 1
     assert L.iq_attn_supported(1025, 16) == 1
-    assert L.iq_attn_supported(1025, 64) == 0   # backward images exceed LDS: documented limit
+    assert L.iq_attn_supported(1025, 32) == 1 and L.iq_attn_supported(1025, 64) == 1    # chunked backward
+    assert L.iq_attn_supported(4097, 64) == 0   # lse / delta of the whole sequence stay in LDS: documented limit
     assert L.iq_attn_supported(64, 48) == 0
+
+
+@pytest.mark.parametrize("S,H,dh,Bf,per_head", [(65, 8, 16, 2, False), (197, 3, 64, 2, True), (40, 2, 32, 3, True),
+                                                 (600, 2, 64, 1, False)])
+def test_attention_mask_branch(L, S, H, dh, Bf, per_head):
+    """scale_dot_product_attention.py:30-31: score.masked_fill(mask == 0, -10000) after the 1/sqrt(dh) scaling -- no
+    reference caller passes a mask, the branch is part of the layer's surface.  Forward, log-sum-exp and backward
+    (masked_fill passes no gradient) against fp64 torch; one query row is fully masked (uniform softmax)."""
+    N = _N()
+    D = H * dh
+    g = torch.Generator(device="cuda").manual_seed(S * 7 + dh)
+    qkv = bf(torch.randn(Bf * S, 3 * D, device=dev(), generator=g))
+    mask = (torch.rand(Bf, H if per_head else 1, S, S, device=dev(), generator=g) > 0.3)
+    mask[:, :, 3, :] = False                       # a fully masked row
+    mk = mask.to(torch.uint8).contiguous()
+    hs = S * S if per_head and H > 1 else 0
+    out = torch.empty(Bf * S, D, dtype=torch.bfloat16, device=dev())
+    lse = torch.empty(Bf, H, S, device=dev())
+    N.check(L.iq_attn_fwd_masked(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), mk.data_ptr(), hs, Bf, S, H, dh,
+                                 stream()), "attn_fwd_masked")
+    qr = qkv.double().requires_grad_(True)
+    q, k, v = [t.view(Bf, S, H, dh).transpose(1, 2) for t in qr.view(Bf, S, 3, D).unbind(2)]
+    sc = (q @ k.transpose(2, 3)) / math.sqrt(dh)
+    sc = sc.masked_fill(mask == 0, -10000)
+    oref = (torch.softmax(sc, dim=-1) @ v).transpose(1, 2).reshape(Bf * S, D)
+    close_bf16(out, oref.detach(), "masked attn out", rel=2 ** -6)
+    close_f32(lse, torch.logsumexp(sc, dim=-1).detach(), "masked lse", 2e-3)
+    dout = bf(torch.randn(Bf * S, D, device=dev(), generator=g))
+    dqkv = torch.zeros_like(qkv)
+    N.check(L.iq_attn_bwd_masked(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                 mk.data_ptr(), hs, Bf, S, H, dh, stream()), "attn_bwd_masked")
+    oref.backward(dout.double())
+    gref = qr.grad
+    scale = gref.abs().max().item()
+    err = (dqkv.double() - gref).abs()
+    assert err.max().item() <= 0.02 * scale + 1e-6, f"masked attn bwd max err {err.max().item():.4g} scale {scale:.4g}"
+    assert (err.pow(2).sum() / gref.pow(2).sum()).sqrt().item() < 8e-3
 
 
 def test_attention_all_scores_very_negative_stays_finite(L):

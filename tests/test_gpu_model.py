@@ -5,8 +5,9 @@ tests/test_oracle_golden.py).
 Stated floating-point tolerance of the bf16 path (BASELINE.json north_star "within a stated fp tolerance"):
   logits ........ |err| <= 3e-2 absolute (logit range here ~ +-1.5) and identical argmax
   loss .......... |err| <= 1e-2
-  gradients ..... per parameter, ||g - g_ref|| <= 10% of ||g_ref|| (+ 2e-3 of the global gradient norm for
-                  parameters whose true gradient is ~0, e.g. the K bias), global norm within 3%.
+  gradients ..... per parameter, ||g - g_ref|| <= 5% of ||g_ref|| (12% for ffn.linear1, see below) (+ 2e-3 of the
+                  global gradient norm for parameters whose true gradient is ~0, e.g. the K bias), global norm
+                  within 3%.  The limits are ~2x the measured errors, so a regression in any one kernel shows.
                   Measured: 1.5-3% everywhere except ffn.linear1 (4-8%): the ReLU mask is taken from the bf16
                   hidden activation, and the ~0.3% of pre-activations with |pre| below the bf16 forward error
                   flip sign relative to the fp32 reference; a flipped unit changes its gradient entry by 100%,
@@ -28,8 +29,15 @@ pytestmark = pytest.mark.gpu
 
 LOGIT_ATOL = 3e-2
 LOSS_ATOL = 1e-2
-GRAD_REL = 1e-1
+GRAD_REL = 5e-2            # every parameter class but ffn.linear1
+GRAD_REL_FFN1 = 12e-2      # ffn.linear1.{weight,bias}: ReLU-mask sign flips of a bf16 forward (docstring)
 GRAD_ABS_OF_TOTAL = 2e-3
+# deep stacks: per-layer bf16 rounding accumulates through 12 / 9 post-norm layers (logit scale ~1.5)
+DEEP = {"vit_tiny224_L12": 5e-2, "rawiq_Cp_L9": 5e-2, "rawiq_C_L6": 4e-2, "vit_base_L2": 4e-2}
+
+
+def grad_rel(key):
+    return GRAD_REL_FFN1 if "ffn.linear1" in key else GRAD_REL
 
 
 def dev():
@@ -80,8 +88,10 @@ def test_logits_loss_and_grads_match_reference(name):
         logits = m(x)
     ref = torch.from_numpy(z["logits"])
     err = (logits.cpu() - ref).abs().max().item()
-    assert err <= LOGIT_ATOL, f"{name}: logits max err {err:.4g}"
-    assert torch.equal(logits.cpu().argmax(1), ref.argmax(1))
+    assert err <= DEEP.get(name, LOGIT_ATOL), f"{name}: logits max err {err:.4g}"
+    top2 = ref.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2 * DEEP.get(name, LOGIT_ATOL)      # argmax must agree wherever it is not a near tie
+    assert torch.equal(logits.cpu().argmax(1)[clear], ref.argmax(1)[clear])
     # state survived the re-homing into the flat buffer
     for k, v in m.state_dict().items():
         assert torch.equal(v.cpu(), sd[k]), k
@@ -101,7 +111,7 @@ def test_logits_loss_and_grads_match_reference(name):
         assert p.grad is not None, k
         g, r = p.grad.cpu().double(), gref[k].double()
         e = (g - r).norm().item()
-        lim = GRAD_REL * r.norm().item() + GRAD_ABS_OF_TOTAL * total_ref
+        lim = grad_rel(k) * r.norm().item() + GRAD_ABS_OF_TOTAL * total_ref
         if e / lim > worst[0]:
             worst = (e / lim, k)
         assert e <= lim, f"{name}: grad {k}: ||err|| {e:.4g} > {lim:.4g} (||ref|| {r.norm().item():.4g})"
@@ -110,7 +120,13 @@ def test_logits_loss_and_grads_match_reference(name):
         if key.startswith("g:"):
             r = torch.from_numpy(z[key]).double()
             g = dict(m.named_parameters())[key[2:]].grad.cpu().double()
-            assert (g - r).norm().item() <= GRAD_REL * r.norm().item() + GRAD_ABS_OF_TOTAL * total_ref, key
+            assert (g - r).norm().item() <= grad_rel(key) * r.norm().item() + GRAD_ABS_OF_TOTAL * total_ref, key
+    # per-parameter gradient norms the REFERENCE produced (every fixture carries them, full depth included)
+    keys = [str(k) for k in z["keys"]]
+    named = dict(m.named_parameters())
+    for k, l2 in zip(keys, z["grad_l2"]):
+        got = named[k].grad.double().norm().item()
+        assert abs(got - float(l2)) <= grad_rel(k) * float(l2) + GRAD_ABS_OF_TOTAL * total_ref, (k, got, float(l2))
 
 
 def test_reference_smoke_shapes():
@@ -160,8 +176,10 @@ def test_encoder_surface_and_errors():
         nc.get_cls_token_output(torch.zeros(1, 2, 256, device=d))
     with pytest.raises(P.IqError, match="no CPU fallback"):
         m(torch.zeros(1, 2, 1024))
-    with pytest.raises(NotImplementedError):
-        m.encoder.layers[0].norm1(torch.zeros(1, 1, 128, device=d))
+    # sub-layers run on their own (per-op C ABI): tests/test_gpu_sublayers.py
+    assert m.encoder.layers[0].norm1(torch.zeros(1, 1, 128, device=d)).shape == (1, 1, 128)
+    # model and encoder share ONE plan / ONE flat parameter buffer: the encoder call above did not re-home anything
+    assert m.native_plan().is_bound(d) and m.encoder._plan is None
 
 
 def test_encoder_backward_from_sequence_output():
@@ -182,7 +200,7 @@ def test_encoder_backward_from_sequence_output():
     for k, p in m.encoder.named_parameters():
         r = leaf["encoder." + k].grad.double()
         e = (p.grad.cpu().double() - r).norm().item()
-        assert e <= GRAD_REL * r.norm().item() + 0.05, (k, e, r.norm().item())
+        assert e <= grad_rel(k) * r.norm().item() + 0.05, (k, e, r.norm().item())
 
 
 def test_dropout_training_mode():
@@ -307,3 +325,69 @@ def test_full_size_properties_vit_tiny():
     ref = O.model_forward(cfg, sd, x[:3].cpu())
     assert (a[:3].cpu() - ref).abs().max().item() <= 5e-2          # 12 layers deep
     assert torch.equal(a[:3].cpu().argmax(1), ref.argmax(1))
+
+
+FULL = {
+    "B": ("vit", dict(in_channels=1, img_size_h=224, img_size_w=224, patch_size=16, num_classes=19, d_model=192,
+                      n_head=3, n_layers=12, ffn_hidden=768), 256),
+    "C": ("rawiq", dict(in_channels=2, seq_length=1024, num_classes=19, d_model=128, n_head=8, n_layers=6,
+                        ffn_hidden=1024, use_cls_token=True, embedding_type="segment", segment_size=16), 256),
+    "Cp": ("rawiq", dict(in_channels=2, seq_length=1024, num_classes=19, d_model=256, n_head=8, n_layers=9,
+                         ffn_hidden=1024, use_cls_token=True, embedding_type="segment", segment_size=16), 128),
+    "D_L2": ("vit", dict(in_channels=1, img_size_h=224, img_size_w=224, patch_size=16, num_classes=19, d_model=768,
+                         n_head=12, n_layers=2, ffn_hidden=3072), 128),
+}
+
+
+@pytest.mark.parametrize("cid", sorted(FULL))
+def test_full_batch_training_step_properties(cid):
+    """The benchmarked configurations at their benchmarked batch (BASELINE.json configs[1..3]; ViT-Base's share at 2
+    layers), where the oracle cannot follow in seconds -- size-independent properties of one whole training step:
+      * every gradient is finite and the gradient norm is positive;
+      * the flat gradient does not depend on the order of the frames in the batch (frames are independent; the
+        weight-gradient sums run in a different order, so equality is to fp32 summation error, not bit exact);
+      * the gradient of a batch is the mean of the gradients of its halves (linearity of the mean loss);
+      * hipGraph replay of the step lands on the same parameters as eager launches, bit for bit (dropout ON)."""
+    from vit_vs_raw_iq_amd.trainer import FusedTrainer
+    d = dev()
+    kind, kw, B = FULL[cid]
+    torch.manual_seed(11)
+    m = build(kind, kw).to(d).train()
+    g = torch.Generator().manual_seed(12)
+    shape = (B, kw["in_channels"], kw["img_size_h"], kw["img_size_w"]) if kind == "vit" else (B, kw["in_channels"], kw["seq_length"])
+    x = torch.randn(*shape, generator=g).to(d)
+    y = torch.randint(0, kw["num_classes"], (B,), generator=g).to(d)
+    crit = torch.nn.CrossEntropyLoss(label_smoothing=0.1)
+
+    def flat_grad(xb, yb):
+        for p in m.parameters():
+            p.grad = None
+        crit(m(xb), yb).backward()
+        return torch.cat([p.grad.reshape(-1) for p in m.parameters()]).double()
+
+    g_all = flat_grad(x, y)
+    assert torch.isfinite(g_all).all() and g_all.norm().item() > 0
+    perm = torch.randperm(B, generator=g).to(d)
+    g_perm = flat_grad(x[perm], y[perm])
+    rel = ((g_all - g_perm).norm() / g_all.norm()).item()
+    assert rel < 2e-3, f"{cid}: gradient depends on the frame order ({rel:.3g})"
+    h = B // 2
+    g_half = 0.5 * (flat_grad(x[:h], y[:h]) + flat_grad(x[h:], y[h:]))
+    rel = ((g_all - g_half).norm() / g_all.norm()).item()
+    assert rel < 2e-3, f"{cid}: batch gradient != mean of half-batch gradients ({rel:.3g})"
+    # graph == eager over three fused steps, dropout ON (device-side step counter, regenerated masks)
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    outs = []
+    for use_graph in (False, True):
+        mm = build(kind, kw, drop_prob=0.1)
+        mm.load_state_dict(sd0)
+        mm.to(d).train()
+        tr = FusedTrainer(mm, lr=1e-3, weight_decay=1e-3, use_graph=use_graph, dropout_seed=21)
+        for _ in range(3):
+            tr.step(x, y)
+        loss, _, frames = tr.read_stats()
+        assert frames == 3 * B and math.isfinite(loss)
+        outs.append({k: v.detach().clone() for k, v in mm.state_dict().items()})
+        del tr, mm
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), f"{cid}: graph replay diverged from eager on {k}"

@@ -150,3 +150,34 @@ def test_device_input_pipeline_matches_cpu_preprocessing_bitwise():
     assert torch.equal(b.cpu(), torch.from_numpy(D.preprocess_reference(X[256:512], st, "vit")))
     with pytest.raises(ValueError):
         D.DeviceInputPipeline(st, "vit", batch=8, h=64, w=64)           # needs 2048 samples per channel
+
+
+def test_compare_run_writes_both_reports_where_compare_models_reads_them(tmp_path):
+    """scripts/compare_run.py trains both families, evaluates, and writes the two reports at the relative paths
+    Transformer_Thesis/compare_models.py:402-403 hard-codes; its three regexes (:39, :44, :49) must parse them."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    dev()
+    out = tmp_path / "cmp"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "compare_run.py"), "--out", str(out), "--frames",
+                        "2280", "--epochs", "2", "--batch", "64", "--small"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    summary = json.loads(r.stdout.strip().splitlines()[-1])
+    paths = {"ViT": out / "ViT/result/checkpoints/production_v2/evaluation/test_classification_report.txt",
+             "transformer_rawIQ": out / "transformer_rawIQ/result/checkpoints/exp_L9_H8_F1024_W1e-3/evaluation/test_classification_report.txt"}
+    for name, path in paths.items():
+        content = path.read_text()
+        overall = float(re.search(r'Overall Accuracy:\s+([\d.]+)%', content).group(1))
+        assert abs(overall - 100 * summary[name]["overall_accuracy"]) < 0.006
+        snr = {int(s): float(a) for s, a in re.findall(r'SNR\s+([-+]\d+)\s+dB:\s+([\d.]+)%', content)}
+        assert set(snr) == {-8, 0, 8}
+        rows = {}
+        for line in content.split('\n'):
+            mt = re.match(r'^\s*(\w+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(\d+)', line)
+            if mt and mt.group(1) not in ('accuracy', 'macro', 'weighted'):
+                rows[mt.group(1)] = int(mt.group(5))
+        assert len(rows) == 19 and sum(rows.values()) > 300
+        assert (path.parent.parent / "model_final.pth").exists()

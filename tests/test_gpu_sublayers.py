@@ -1,0 +1,140 @@
+"""GPU (MI355X): the reference's layer modules run on their own -- LayerNorm, ScaleDotProductAttention (with the
+mask branch), MultiHeadAttention, PositionwiseFeedForward, EncoderLayer, the embeddings -- through the per-op C ABI
+(vit-vs-raw-iq_amd/functional.py), against the reference's own outputs (tests/golden/sublayers.npz, written by
+tests/golden/make_golden.py from the reference modules) and, for gradients, against the CPU oracle's layer functions.
+
+Stated tolerance (bf16 operands, fp32 accumulate, fp32 in / out): |err| <= 3e-2 absolute on O(1) layer outputs,
+gradients within 5 % relative L2."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import iq_oracle as O
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+ATOL = 3e-2
+
+
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def fixture():
+    z = np.load(os.path.join(GOLDEN, "sublayers.npz"), allow_pickle=False)
+    D, F, H, B, S = [int(v) for v in z["dims"]]
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    return z, sd, (D, F, H, B, S)
+
+
+def layer_on_gpu(d):
+    import vit_vs_raw_iq_amd as P
+    z, sd, (D, F, H, B, S) = fixture()
+    layer = P.EncoderLayer(d_model=D, ffn_hidden=F, n_head=H, drop_prob=0.0)
+    layer.load_state_dict(sd)
+    return layer.to(d).eval(), z, sd, (D, F, H, B, S)
+
+
+def test_encoder_layer_and_its_parts_match_the_reference_outputs():
+    d = dev()
+    layer, z, sd, (D, F, H, B, S) = layer_on_gpu(d)
+    x = torch.from_numpy(z["x"]).to(d)
+    mask = torch.from_numpy(z["mask"]).to(d)
+    seen = []
+    hook = layer.norm1.register_forward_hook(lambda m, i, o: seen.append(o.detach()))     # hooks fire on sub-layers
+    with torch.no_grad():
+        got = {"out": layer(x, None), "out_masked": layer(x, mask), "mha": layer.attention(q=x, k=x, v=x),
+               "mha_masked": layer.attention(q=x, k=x, v=x, mask=mask), "ffn": layer.ffn(x), "ln": layer.norm1(x)}
+        q = layer.attention.split(layer.attention.w_q(x))
+        k = layer.attention.split(layer.attention.w_k(x))
+        v = layer.attention.split(layer.attention.w_v(x))
+        core, score = layer.attention.attention(q, k, v, mask=mask)
+    hook.remove()
+    assert len(seen) == 3
+    for name, t in got.items():
+        ref = torch.from_numpy(z[name])
+        assert t.shape == ref.shape and t.dtype == torch.float32
+        err = (t.cpu() - ref).abs().max().item()
+        assert err <= ATOL, f"{name}: max err {err:.4g}"
+    assert (score.cpu() - torch.from_numpy(z["score_masked"])).abs().max().item() <= 2e-2
+    # the attention core consumed bf16 q/k/v produced by the native linear: compare at the same tolerance
+    assert (core.cpu() - torch.from_numpy(z["core_masked"])).abs().max().item() <= ATOL
+    # the fully masked query row attends uniformly
+    assert torch.allclose(score[:, :, 2, :].cpu(), torch.full((B, H, S), 1.0 / S), atol=1e-5)
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_encoder_layer_autograd_matches_the_oracle(masked):
+    d = dev()
+    layer, z, sd, (D, F, H, B, S) = layer_on_gpu(d)
+    layer.train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.from_numpy(z["x"])
+    w = torch.randn(B, S, D, generator=g)
+    mask = torch.from_numpy(z["mask"]) if masked else None
+    xg = x.clone().to(d).requires_grad_(True)
+    out = layer(xg, mask.to(d) if masked else None)
+    (out * w.to(d)).sum().backward()
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    (O.encoder_layer(leaf, "", xr, H, mask=mask) * w).sum().backward()
+    rel = ((xg.grad.cpu() - xr.grad).norm() / xr.grad.norm()).item()
+    assert rel < 5e-2, f"dx rel err {rel:.3g}"
+    for k, p in layer.named_parameters():
+        r = leaf[k].grad
+        e = (p.grad.cpu() - r).norm().item()
+        assert e <= 5e-2 * r.norm().item() + 2e-3 * xr.grad.norm().item(), (k, e, r.norm().item())
+
+
+def test_stand_alone_embeddings_and_positional_encoding():
+    d = dev()
+    import vit_vs_raw_iq_amd as P
+    torch.manual_seed(1)
+    pe = P.PatchEmbedding(in_channels=2, patch_size=8, embedding_dim=64).to(d)
+    x = torch.randn(3, 2, 16, 48)
+    with torch.no_grad():
+        got = pe(x.to(d))
+        ref = torch.nn.functional.conv2d(x, pe.projection.weight.cpu(), pe.projection.bias.cpu(), stride=8).flatten(2).transpose(1, 2)
+    assert got.shape == ref.shape == (3, 12, 64)
+    assert (got.cpu() - ref).abs().max().item() <= ATOL
+    for method, seg in (("segment", 16), ("conv1d", None)):
+        se = P.SequenceEmbedding(in_channels=2, embedding_dim=64, method=method, segment_size=seg).to(d)
+        xs = torch.randn(2, 2, 128)
+        with torch.no_grad():
+            got = se(xs.to(d))
+            ref = torch.nn.functional.conv1d(xs, se.projection.weight.cpu(), se.projection.bias.cpu(),
+                                             stride=seg or 1).transpose(1, 2)
+        assert got.shape == ref.shape and (got.cpu() - ref).abs().max().item() <= ATOL, method
+    from vit_vs_raw_iq_amd.modules import PositionalEncodingRawIQ, PositionalEncodingViT
+    pr = PositionalEncodingRawIQ(d_model=32, max_len=9).to(d)
+    assert torch.equal(pr(torch.zeros(2, 9, 32, device=d))[0].cpu(), pr.encoding.cpu())
+    with pytest.raises(ValueError, match="exceeds maximum length"):
+        pr(torch.zeros(1, 10, 32, device=d))
+    pv = PositionalEncodingViT(d_model=32, max_len=5).to(d)
+    assert torch.equal(pv(torch.zeros(1, 5, 32, device=d))[0].cpu(), pv.encoding.cpu())
+
+
+def test_encoder_src_mask_runs_layer_by_layer_and_matches_the_plan_when_all_ones():
+    """Encoder.forward(src, src_mask) (V/models/encoder.py:34, R/models/encoder.py:86): an all-ones mask must reproduce
+    the fused plan's encoder output; a real mask changes it."""
+    d = dev()
+    import vit_vs_raw_iq_amd as P
+    torch.manual_seed(2)
+    m = P.AMCTransformerRawIQ(in_channels=2, seq_length=256, num_classes=4, d_model=64, n_head=4, n_layers=2,
+                              ffn_hidden=128, drop_prob=0.0, device="cuda", segment_size=16).to(d).eval()
+    x = torch.randn(3, 2, 256, device=d)
+    S = 17
+    with torch.no_grad():
+        plan_out = m.encoder(x)
+        ones = m.encoder(x, torch.ones(3, 1, S, S, device=d))
+        half = torch.ones(3, 1, S, S, device=d)
+        half[:, :, :, S // 2:] = 0
+        masked = m.encoder(x, half)
+    assert (plan_out - ones).abs().max().item() <= 6e-2
+    assert (plan_out - masked).abs().max().item() > 1e-2
+    with pytest.raises(P.IqError, match="no CPU fallback"):
+        m.encoder.layers[0].norm1(torch.zeros(1, 1, 64))

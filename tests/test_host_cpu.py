@@ -61,7 +61,8 @@ def test_host_only_queries_work_without_a_gpu():
     import vit_vs_raw_iq_amd._native as N
     L = N.lib()
     assert L.iq_ln_supported(192) == 1 and L.iq_ln_supported(20) == 0
-    assert L.iq_attn_supported(197, 64) == 1 and L.iq_attn_supported(2000, 64) == 0
+    assert L.iq_attn_supported(197, 64) == 1 and L.iq_attn_supported(1025, 64) == 1 and L.iq_attn_supported(5000, 64) == 0
+    assert L.iq_attn_supported(197, 48) == 0
     assert L.iq_wgrad_ws_bytes(50432, 768, 192) > 0
     cfg = N.ModelCfg(kind=0, in_channels=1, img_h=224, img_w=224, patch=16, seq_length=0, conv_k=0, use_cls=1,
                      num_classes=19, d_model=192, n_head=3, n_layers=12, ffn_hidden=768, drop_prob=0.1)

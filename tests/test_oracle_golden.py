@@ -109,3 +109,21 @@ def test_dropout_train_mode_statistics():
     y = O._dropout(x, 0.5, True)
     assert abs(float((y == 0).float().mean()) - 0.5) < 0.02
     assert abs(float(y.mean()) - 1.0) < 0.05
+
+
+def test_oracle_layer_functions_match_the_reference_layer_outputs():
+    """tests/golden/sublayers.npz holds the reference's own EncoderLayer / MultiHeadAttention / FFN / LayerNorm outputs
+    (mask branch included, scale_dot_product_attention.py:30-31); the oracle's layer-level functions must reproduce them."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "sublayers.npz"), allow_pickle=False)
+    D, F, H, B, S = [int(v) for v in z["dims"]]
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    x = torch.from_numpy(z["x"])
+    mask = torch.from_numpy(z["mask"])
+    pairs = {"out": O.encoder_layer(sd, "", x, H), "out_masked": O.encoder_layer(sd, "", x, H, mask=mask),
+             "mha": O.multi_head_attention(sd, "attention.", x, H), "mha_masked": O.multi_head_attention(sd, "attention.", x, H, mask),
+             "ffn": O.feed_forward(sd, "ffn.", x), "ln": O.custom_layer_norm(x, sd["norm1.gamma"], sd["norm1.beta"])}
+    for name, got in pairs.items():
+        assert torch.allclose(got, torch.from_numpy(z[name]), atol=2e-6, rtol=1e-5), name

@@ -66,6 +66,8 @@ SIGNATURES = {
     "iq_attn_supported": (_I, [_I, _I]),
     "iq_attn_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "iq_attn_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "iq_attn_fwd_masked": (_I, [_P, _P, _P, _P, C.c_long, _I, _I, _I, _I, _P]),
+    "iq_attn_bwd_masked": (_I, [_P, _P, _P, _P, _P, _P, C.c_long, _I, _I, _I, _I, _P]),
     "iq_frames_preprocess": (_I, [_P, _P, _I, _I, _I, C.POINTER(C.c_float), _P]),
     "iq_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "iq_cls_rows": (_I, [_P, _P, _P, _I, _I, _I, C.POINTER(Dropout), _P]),
@@ -89,6 +91,7 @@ SIGNATURES = {
     "iq_model_shadow_bytes": (_Z, [_P]),
     "iq_model_workspace_bytes": (_Z, [_P, _I, _I]),
     "iq_model_bind": (_I, [_P, _P, _P, _P, _P]),
+    "iq_model_bind_step_counter": (_I, [_P, _P]),
     "iq_model_refresh_shadow": (_I, [_P, _P]),
     "iq_model_refresh_transposed": (_I, [_P, _P]),
     "iq_model_forward": (_I, [_P, _P, _I, _P, _Z, _I, _U64, _U32, _P, _P, _P]),

@@ -56,7 +56,8 @@ def load_optimizer_state_dict(trainer, sd: Dict) -> None:
     trainer.steps = steps
     trainer.plan.step = steps
     trainer.dyn[1] = float(steps)
-    trainer._graph = None             # hyper-parameters baked into a captured graph may have changed
+    trainer.plan.ctr_value = -1       # the device-side dropout step is re-synchronised by the next step()
+    trainer._graphs = None            # hyper-parameters baked into a captured graph may have changed
 
 
 def save_checkpoint(filepath, model, trainer=None, optimizer=None, scheduler=None, epoch: int = 0,
@@ -75,13 +76,17 @@ def save_checkpoint(filepath, model, trainer=None, optimizer=None, scheduler=Non
     torch.save(ckpt, filepath)
 
 
-def load_checkpoint(filepath, model, trainer=None, optimizer=None, scheduler=None) -> Dict:
-    ckpt = torch.load(filepath, map_location="cpu", weights_only=False)   # our own / user-trusted file
+def load_checkpoint(filepath, model, trainer=None, optimizer=None, scheduler=None, trust: bool = False) -> Dict:
+    """A checkpoint holds tensors, numbers, strings, lists and dicts only, so it is read with the loader that executes
+    nothing from the file (weights_only=True) -- reference-trained and third-party .pth files are not trusted code.
+    `trust=True` falls back to full unpickling for a file you wrote yourself that carries other Python objects."""
+    ckpt = torch.load(filepath, map_location="cpu", weights_only=not trust)
     model.load_state_dict(ckpt["model_state_dict"])
+    if trainer is not None:
+        trainer.plan.mark_dirty()
+        trainer.plan.ensure(trainer.device)      # pushes the loaded fp32 values into the bf16 shadows, optimizer state or not
     if "optimizer_state_dict" in ckpt:
         if trainer is not None:
-            plan = trainer.plan
-            plan.ensure(trainer.device)          # pushes the loaded fp32 values into the bf16 shadows
             load_optimizer_state_dict(trainer, ckpt["optimizer_state_dict"])
         elif optimizer is not None:
             optimizer.load_state_dict(ckpt["optimizer_state_dict"])

@@ -106,10 +106,14 @@ __device__ __forceinline__ float group4_sum(float v) {
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-template <int DH>
+// MASKED: optional `mask` (uint8, 0 = masked) as (B, 1 | H, S, S): a masked position's scaled score is -10000
+// (scale_dot_product_attention.py:30-31: masked_fill AFTER the 1/sqrt(dh) scaling), `masked_raw` = -10000 sqrt(dh) is
+// that value in the unscaled domain the kernel keeps scores in.
+template <int DH, bool MASKED>
 __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                               float* __restrict__ lse, int S, int H, int kchunk,
-                                                               float scale_log2) {
+                                                               float* __restrict__ lse, const uint8_t* __restrict__ mask,
+                                                               long mask_hstride, int S, int H, int kchunk,
+                                                               float scale_log2, float masked_raw) {
   using C = AttCfg<DH>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16* Ks = reinterpret_cast<bf16*>(smem);
@@ -121,6 +125,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16* __res
   const bf16* qb = qkv + (long)b * S * ldg + h * DH;
   const bf16* kb_ = qb + D;
   const bf16* vb_ = qb + 2 * D;
+  const uint8_t* mk = MASKED ? mask + (long)b * (mask_hstride ? (long)H * S * S : (long)S * S) + h * mask_hstride : nullptr;
   const int qtiles = (S + 31) / 32, npass = (qtiles + ATT_WAVES - 1) / ATT_WAVES, nstage = (S + kchunk - 1) / kchunk;
 
   for (int pass = 0; pass < npass; ++pass) {
@@ -172,6 +177,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16* __res
               for (int r = 0; r < 4; ++r) {
                 const int key = k0 + kb + kt * 16 + 4 * g + r;
                 float x = sc[u][kt][r];               // raw score: the positive scale commutes with max and is folded
+                if (MASKED) {
+                  const int q = qt * 32 + u * 16 + c16;
+                  if (key < S && q < S && !mk[(long)q * S + key]) x = masked_raw;
+                }
                 x = key < S ? x : NEG_BIG;            // into the exp2 argument below (one fma instead of mul + sub)
                 sc[u][kt][r] = x;
                 mx = fmaxf(mx, x);
@@ -227,16 +236,21 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16* __res
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
-template <int DH>
-__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+// The staged side of each phase (phase A: Q and dO; phase B: K and V) lives in LDS `chunk` rows at a time.  One chunk
+// covers the whole sequence for every training configuration (S <= 197 at dh 64, S <= 1025 at dh 16): then each image is
+// staged exactly once, as before.  Longer sequences (embedding_type='conv1d', S = 1025, at dh 32 / 64: R/models/encoder.py:34-41)
+// sweep the chunks once per group of 8 units / query blocks; the re-staged rows come from L2.
+template <int DH, bool MASKED>
+__global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                                const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                               bf16* __restrict__ dqkv, int S, int H, int spad,
-                                                               float scale) {
+                                                               bf16* __restrict__ dqkv, const uint8_t* __restrict__ mask,
+                                                               long mask_hstride, int S, int H, int spad, int chunk,
+                                                               float scale, float masked_raw) {
   using C = AttCfg<DH>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16* I0 = reinterpret_cast<bf16*>(smem);            // phase A: Q   | phase B: K
-  bf16* I1 = I0 + spad * C::LD;                        // phase A: dO  | phase B: V
-  float* lse_s = reinterpret_cast<float*>(I1 + spad * C::LD);   // [spad], pre-multiplied by log2(e)
+  bf16* I1 = I0 + chunk * C::LD;                       // phase A: dO  | phase B: V
+  float* lse_s = reinterpret_cast<float*>(I1 + chunk * C::LD);   // [spad], pre-multiplied by log2(e)
   float* del_s = lse_s + spad;                                   // [spad]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -248,20 +262,26 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const bf16* __res
   const bf16* ob = out + (long)b * S * D + h * DH;
   const bf16* dob = dout + (long)b * S * D + h * DH;
   bf16* dqb = dqkv + (long)b * S * ldg + h * DH;
+  const uint8_t* mk = MASKED ? mask + (long)b * (mask_hstride ? (long)H * S * S : (long)S * S) + h * mask_hstride : nullptr;
   const float scale_log2 = scale * LOG2E;
   const int nblk = spad / 32;
+  const int nchunk = (spad + chunk - 1) / chunk;
+  const bool single = nchunk == 1;
 
-  // ---- stage Q, dO; delta[q] = sum_d dO*O; lse ------------------------------------------------
-  stage_rows<DH>(I0, qb, ldg, 0, spad, S, tid);
-  stage_rows<DH>(I1, dob, (long)D, 0, spad, S, tid);
-  __syncthreads();
-  // delta from the dO image just staged (dO is fetched from HBM once, not twice); O comes from HBM, its only use
+  // ---- delta[q] = sum_d dO*O; lse ---------------------------------------------------------------
+  if (single) {
+    stage_rows<DH>(I0, qb, ldg, 0, spad, S, tid);
+    stage_rows<DH>(I1, dob, (long)D, 0, spad, S, tid);
+    __syncthreads();
+  }
+  // single chunk: delta from the dO image just staged (dO is fetched from HBM once, not twice); O comes from HBM, its only use
   for (int q = tid; q < spad; q += ATT_THREADS) {
     float dl = 0.f, ls = 0.f;
     if (q < S) {
 #pragma unroll
       for (int c = 0; c < C::CPR; ++c) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(I1 + q * C::LD + c * 8);
+        const bf16x8 a = single ? *reinterpret_cast<const bf16x8*>(I1 + q * C::LD + c * 8)
+                                : *reinterpret_cast<const bf16x8*>(dob + (long)q * D + c * 8);
         const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(ob + (long)q * D + c * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dl += (float)a[e] * (float)o8[e];
@@ -277,52 +297,67 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const bf16* __res
   // (16-key units keep the kernel at <= 128 VGPRs, so two 8-wave workgroups share a CU and one's staging /
   //  dependency stalls overlap the other's MFMAs; 32-key units needed 195 VGPRs = one workgroup per CU.)
   const int nunit = (S + 15) / 16;      // units made only of padding keys are skipped
-  for (int unit = wave; unit < nunit; unit += ATT_WAVES) {
+  for (int ug = 0; ug * ATT_WAVES < nunit; ++ug) {
+    const int unit = ug * ATT_WAVES + wave;
+    const bool have = unit < nunit;       // wave-uniform
     bf16x8 kf[C::KS], vf[C::KS];
 #pragma unroll
     for (int s = 0; s < C::KS; ++s) {
-      kf[s] = row_frag_gmem<DH>(kb_, ldg, unit * 16 + c16, S, s, lane);
-      vf[s] = row_frag_gmem<DH>(vb_, ldg, unit * 16 + c16, S, s, lane);
+      kf[s] = row_frag_gmem<DH>(kb_, ldg, unit * 16 + c16, have ? S : 0, s, lane);
+      vf[s] = row_frag_gmem<DH>(vb_, ldg, unit * 16 + c16, have ? S : 0, s, lane);
     }
     f32x4 dv[C::DT], dk[C::DT];
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) { dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const int key = unit * 16 + c16;
     const bool unit_partial = unit * 16 + 16 > S;       // wave-uniform
-    for (int qblk = 0; qblk < nblk; ++qblk) {
-      f32x4 p[2], ds[2];   // [u]
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < C::KS; ++s) {
-          const bf16x8 qa = row_frag_lds<DH>(I0, qblk * 32 + u * 16 + c16, s, lane);
-          const bf16x8 da = row_frag_lds<DH>(I1, qblk * 32 + u * 16 + c16, s, lane);
-          sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[s], sa, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[s], dp, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int q = qblk * 32 + u * 16 + 4 * g + r;
-          // Padded QUERY rows need no mask: Q = dO = 0 and lse = delta = 0 there, so P = 1 and dS = 0 multiply zeros.
-          // Padded KEYS do (only this wave's unit can hold them): P = exp2(-lse) is unbounded when a row's scores are
-          // all very negative, and inf * 0 would poison dQ.
-          float pv = fast_exp2(sa[r] * scale_log2 - lse_s[q]);
-          if (unit_partial) pv = key < S ? pv : 0.f;
-          p[u][r] = pv;
-          ds[u][r] = pv * (dp[r] - del_s[q]) * scale;
-        }
+    for (int qc = 0; qc < nchunk; ++qc) {
+      const int q0 = qc * chunk;
+      const int rows = min(chunk, spad - q0);
+      if (!single) {
+        __syncthreads();
+        stage_rows<DH>(I0, qb, ldg, q0, rows, S, tid);
+        stage_rows<DH>(I1, dob, (long)D, q0, rows, S, tid);
+        __syncthreads();
       }
-      const bf16x8 pB = pack_b(p[0], p[1]), dsB = pack_b(ds[0], ds[1]);
+      if (!have) continue;
+      for (int ql = 0; ql < rows; ql += 32) {
+        f32x4 p[2], ds[2];   // [u]
 #pragma unroll
-      for (int dt = 0; dt < C::DT; ++dt) {
-        const bf16x8 doT = tr_frag(I1, C::LD, qblk * 32, dt * 16, lane);
-        const bf16x8 qT = tr_frag(I0, C::LD, qblk * 32, dt * 16, lane);
-        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doT, pB, dv[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, dsB, dk[dt], 0, 0, 0);
+        for (int u = 0; u < 2; ++u) {
+          f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < C::KS; ++s) {
+            const bf16x8 qa = row_frag_lds<DH>(I0, ql + u * 16 + c16, s, lane);
+            const bf16x8 da = row_frag_lds<DH>(I1, ql + u * 16 + c16, s, lane);
+            sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[s], sa, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[s], dp, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = q0 + ql + u * 16 + 4 * g + r;
+            // Padded QUERY rows need no mask: Q = dO = 0 and lse = delta = 0 there, so P = 1 and dS = 0 multiply zeros.
+            // Padded KEYS do (only this wave's unit can hold them): P = exp2(-lse) is unbounded when a row's scores are
+            // all very negative, and inf * 0 would poison dQ.
+            bool blocked = false;
+            if (MASKED) blocked = q < S && key < S && !mk[(long)q * S + key];
+            float pv = fast_exp2((blocked ? masked_raw : sa[r]) * scale_log2 - lse_s[q]);
+            if (unit_partial) pv = key < S ? pv : 0.f;
+            p[u][r] = pv;
+            ds[u][r] = blocked ? 0.f : pv * (dp[r] - del_s[q]) * scale;     // masked_fill passes no gradient
+          }
+        }
+        const bf16x8 pB = pack_b(p[0], p[1]), dsB = pack_b(ds[0], ds[1]);
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+          const bf16x8 doT = tr_frag(I1, C::LD, ql, dt * 16, lane);
+          const bf16x8 qT = tr_frag(I0, C::LD, ql, dt * 16, lane);
+          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doT, pB, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, dsB, dk[dt], 0, 0, 0);
+        }
       }
     }
-    if (key < S) {
+    if (have && key < S) {
 #pragma unroll
       for (int dt = 0; dt < C::DT; ++dt) {
         bf16x4 wk, wv;
@@ -335,31 +370,32 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const bf16* __res
   }
 
   // ---- phase B: restage K, V; wave owns 32 queries, sweeps keys; dQ^T in registers ---------------
-  // The wave's query-side fragments (its first query block) come out of the Q / dO images before K and V overwrite
-  // them: Q and dO are fetched from HBM once.  (S > 256: later blocks of a wave fall back to global loads.)
+  // Single chunk: the wave's query-side fragments (its first query block) come out of the Q / dO images before K and V
+  // overwrite them: Q and dO are fetched from HBM once.  (Later blocks of a wave, and every block of a chunked run, use
+  // global loads.)
   bf16x8 qf[2][C::KS], dof[2][C::KS];
+  if (single) {
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int s = 0; s < C::KS; ++s) {
-      const int q = min(wave, nblk - 1) * 32 + u * 16 + c16;
-      qf[u][s] = row_frag_lds<DH>(I0, q, s, lane);
-      dof[u][s] = row_frag_lds<DH>(I1, q, s, lane);
-    }
-  __syncthreads();
-  stage_rows<DH>(I0, kb_, ldg, 0, spad, S, tid);
-  stage_rows<DH>(I1, vb_, ldg, 0, spad, S, tid);
-  __syncthreads();
-  for (int qblk = wave; qblk < nblk; qblk += ATT_WAVES) {
+      for (int s = 0; s < C::KS; ++s) {
+        const int q = min(wave, nblk - 1) * 32 + u * 16 + c16;
+        qf[u][s] = row_frag_lds<DH>(I0, q, s, lane);
+        dof[u][s] = row_frag_lds<DH>(I1, q, s, lane);
+      }
+  }
+  for (int qg = 0; qg * ATT_WAVES < nblk; ++qg) {
+    const int qblk = qg * ATT_WAVES + wave;
+    const bool have = qblk < nblk;          // wave-uniform
     float lq[2], dl[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int q = qblk * 32 + u * 16 + c16;
-      if (qblk != wave) {
+      const int q = min(qblk, nblk - 1) * 32 + u * 16 + c16;
+      if (!single || qg != 0) {
 #pragma unroll
         for (int s = 0; s < C::KS; ++s) {
-          qf[u][s] = row_frag_gmem<DH>(qb, ldg, q, S, s, lane);
-          dof[u][s] = row_frag_gmem<DH>(dob, (long)D, q, S, s, lane);
+          qf[u][s] = row_frag_gmem<DH>(qb, ldg, q, have ? S : 0, s, lane);
+          dof[u][s] = row_frag_gmem<DH>(dob, (long)D, q, have ? S : 0, s, lane);
         }
       }
       lq[u] = lse_s[q];
@@ -370,54 +406,72 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const bf16* __res
     for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
       for (int u = 0; u < 2; ++u) dq[dt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kblk = 0; kblk < nblk; ++kblk) {
-      const bool kblk_partial = kblk * 32 + 32 > S;     // wave-uniform
-      f32x4 ds[2][2];  // [u][kt]
+    for (int kc = 0; kc < nchunk; ++kc) {
+      const int k0 = kc * chunk;
+      const int rows = min(chunk, spad - k0);
+      if (!single || qg == 0) {
+        __syncthreads();
+        stage_rows<DH>(I0, kb_, ldg, k0, rows, S, tid);
+        stage_rows<DH>(I1, vb_, ldg, k0, rows, S, tid);
+        __syncthreads();
+      }
+      if (!have) continue;
+      for (int kl = 0; kl < rows; kl += 32) {
+        const bool kblk_partial = k0 + kl + 32 > S;     // wave-uniform
+        f32x4 ds[2][2];  // [u][kt]
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        bf16x8 ka[C::KS], va[C::KS];
-#pragma unroll
-        for (int s = 0; s < C::KS; ++s) {
-          ka[s] = row_frag_lds<DH>(I0, kblk * 32 + kt * 16 + c16, s, lane);
-          va[s] = row_frag_lds<DH>(I1, kblk * 32 + kt * 16 + c16, s, lane);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < 2; ++kt) {
+          bf16x8 ka[C::KS], va[C::KS];
 #pragma unroll
           for (int s = 0; s < C::KS; ++s) {
-            sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[s], qf[u][s], sa, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[s], dof[u][s], dp, 0, 0, 0);
+            ka[s] = row_frag_lds<DH>(I0, kl + kt * 16 + c16, s, lane);
+            va[s] = row_frag_lds<DH>(I1, kl + kt * 16 + c16, s, lane);
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = kblk * 32 + kt * 16 + 4 * g + r;
-            float pv = fast_exp2(sa[r] * scale_log2 - lq[u]);
-            if (kblk_partial) pv = key < S ? pv : 0.f;          // padded keys: see phase A
-            ds[u][kt][r] = pv * (dp[r] - dl[u]) * scale;
+          for (int u = 0; u < 2; ++u) {
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < C::KS; ++s) {
+              sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[s], qf[u][s], sa, 0, 0, 0);
+              dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[s], dof[u][s], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = k0 + kl + kt * 16 + 4 * g + r;
+              bool blocked = false;
+              if (MASKED) {
+                const int q = qblk * 32 + u * 16 + c16;
+                blocked = q < S && key < S && !mk[(long)q * S + key];
+              }
+              float pv = fast_exp2((blocked ? masked_raw : sa[r]) * scale_log2 - lq[u]);
+              if (kblk_partial) pv = key < S ? pv : 0.f;          // padded keys: see phase A
+              ds[u][kt][r] = blocked ? 0.f : pv * (dp[r] - dl[u]) * scale;
+            }
           }
         }
-      }
-      bf16x8 dsB[2];
+        bf16x8 dsB[2];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) dsB[u] = pack_b(ds[u][0], ds[u][1]);
-#pragma unroll
-      for (int dt = 0; dt < C::DT; ++dt) {
-        const bf16x8 kT = tr_frag(I0, C::LD, kblk * 32, dt * 16, lane);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) dq[dt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, dsB[u], dq[dt][u], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int q = qblk * 32 + u * 16 + c16;
-      if (q < S) {
+        for (int u = 0; u < 2; ++u) dsB[u] = pack_b(ds[u][0], ds[u][1]);
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
-          bf16x4 w;
+          const bf16x8 kT = tr_frag(I0, C::LD, kl, dt * 16, lane);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) w[r] = (bf16)dq[dt][u][r];
-          *reinterpret_cast<bf16x4*>(dqb + (long)q * ldg + dt * 16 + 4 * g) = w;
+          for (int u = 0; u < 2; ++u) dq[dt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, dsB[u], dq[dt][u], 0, 0, 0);
+        }
+      }
+    }
+    if (have) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q = qblk * 32 + u * 16 + c16;
+        if (q < S) {
+#pragma unroll
+          for (int dt = 0; dt < C::DT; ++dt) {
+            bf16x4 w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = (bf16)dq[dt][u][r];
+            *reinterpret_cast<bf16x4*>(dqb + (long)q * ldg + dt * 16 + 4 * g) = w;
+          }
         }
       }
     }
@@ -425,72 +479,106 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const bf16* __res
 }
 
 constexpr size_t ATT_LDS_FWD_BUDGET = 72 * 1024;   // S=197, dh=64 (224 rows) in one stage, 2 WG/CU
-constexpr size_t ATT_LDS_MAX = 160 * 1024;
+constexpr size_t ATT_LDS_BWD_BUDGET = 76 * 1024;   // S=197, dh=64: both 224-row images + statistics, 2 WG/CU
+constexpr int ATT_MAX_S = 4096;                    // lse / delta stay whole in LDS (8 B per padded row)
 
+// rows of the staged side kept in LDS at a time (multiple of 32)
+template <int DH> int bwd_chunk_rows(int S) {
+  const int spad = (S + 31) / 32 * 32;
+  const long room = (long)ATT_LDS_BWD_BUDGET - (long)2 * spad * sizeof(float);
+  int chunk = (int)(room / (2 * AttCfg<DH>::LD * 2)) / 32 * 32;
+  if (chunk > spad) chunk = spad;
+  return chunk;
+}
 template <int DH> size_t bwd_lds_bytes(int S) {
   const int spad = (S + 31) / 32 * 32;
-  return (size_t)2 * spad * AttCfg<DH>::LD * 2 + (size_t)2 * spad * sizeof(float);
+  return (size_t)2 * bwd_chunk_rows<DH>(S) * AttCfg<DH>::LD * 2 + (size_t)2 * spad * sizeof(float);
 }
 
-template <int DH>
-int launch_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, hipStream_t st) {
+template <int DH, bool MASKED>
+int launch_fwd(const void* qkv, void* out, float* lse, const uint8_t* mask, long mask_hstride, int B, int S, int H,
+               hipStream_t st) {
   const int spad = (S + 31) / 32 * 32;
   int kchunk = (int)(ATT_LDS_FWD_BUDGET / (2 * AttCfg<DH>::LD * 2)) / 32 * 32;
   if (kchunk > spad) kchunk = spad;
   const size_t lds = (size_t)2 * kchunk * AttCfg<DH>::LD * 2;
   const float scale_log2 = LOG2E / sqrtf((float)DH);
   if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  attn_fwd_kernel<DH><<<B * H, ATT_THREADS, lds, st>>>((const bf16*)qkv, (bf16*)out, lse, S, H, kchunk, scale_log2);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<DH, MASKED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  attn_fwd_kernel<DH, MASKED><<<B * H, ATT_THREADS, lds, st>>>((const bf16*)qkv, (bf16*)out, lse, mask, mask_hstride, S, H,
+                                                               kchunk, scale_log2, -10000.0f * sqrtf((float)DH));
   return iq_launch_status();
 }
 
-template <int DH>
-int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int S, int H,
-               hipStream_t st) {
+template <int DH, bool MASKED>
+int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, const uint8_t* mask,
+               long mask_hstride, int B, int S, int H, hipStream_t st) {
   const int spad = (S + 31) / 32 * 32;
+  const int chunk = bwd_chunk_rows<DH>(S);
+  if (S > ATT_MAX_S || chunk < 32) return IQ_ERR_UNSUPPORTED;
   const size_t lds = bwd_lds_bytes<DH>(S);
-  if (lds > ATT_LDS_MAX) return IQ_ERR_UNSUPPORTED;
   if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  attn_bwd_kernel<DH><<<B * H, ATT_THREADS, lds, st>>>((const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse,
-                                                       (bf16*)dqkv, S, H, spad, 1.0f / sqrtf((float)DH));
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<DH, MASKED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  attn_bwd_kernel<DH, MASKED><<<B * H, ATT_THREADS, lds, st>>>((const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse,
+                                                               (bf16*)dqkv, mask, mask_hstride, S, H, spad, chunk,
+                                                               1.0f / sqrtf((float)DH), -10000.0f * sqrtf((float)DH));
   return iq_launch_status();
+}
+
+template <bool MASKED>
+int dispatch_fwd(const void* qkv, void* out, float* lse, const uint8_t* mask, long hs, int B, int S, int H, int dh,
+                 hipStream_t st) {
+  switch (dh) {
+    case 16: return launch_fwd<16, MASKED>(qkv, out, lse, mask, hs, B, S, H, st);
+    case 32: return launch_fwd<32, MASKED>(qkv, out, lse, mask, hs, B, S, H, st);
+    case 64: return launch_fwd<64, MASKED>(qkv, out, lse, mask, hs, B, S, H, st);
+    default: return IQ_ERR_UNSUPPORTED;
+  }
+}
+template <bool MASKED>
+int dispatch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, const uint8_t* mask,
+                 long hs, int B, int S, int H, int dh, hipStream_t st) {
+  switch (dh) {
+    case 16: return launch_bwd<16, MASKED>(qkv, out, dout, lse, dqkv, mask, hs, B, S, H, st);
+    case 32: return launch_bwd<32, MASKED>(qkv, out, dout, lse, dqkv, mask, hs, B, S, H, st);
+    case 64: return launch_bwd<64, MASKED>(qkv, out, dout, lse, dqkv, mask, hs, B, S, H, st);
+    default: return IQ_ERR_UNSUPPORTED;
+  }
 }
 
 }  // namespace
 
 extern "C" int iq_attn_supported(int S, int dh) {
-  if (S <= 0) return 0;
-  if (dh == 16) return bwd_lds_bytes<16>(S) <= ATT_LDS_MAX;
-  if (dh == 32) return bwd_lds_bytes<32>(S) <= ATT_LDS_MAX;
-  if (dh == 64) return bwd_lds_bytes<64>(S) <= ATT_LDS_MAX;
-  return 0;
+  if (S <= 0 || S > ATT_MAX_S) return 0;
+  return (dh == 16 || dh == 32 || dh == 64) ? 1 : 0;
 }
 
-extern "C" int iq_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int dh, iq_stream_t stream) {
+extern "C" int iq_attn_fwd_masked(const void* qkv, void* out, float* lse, const uint8_t* mask, long mask_hstride, int B,
+                                  int S, int H, int dh, iq_stream_t stream) {
   if (B <= 0) return IQ_OK;
   if (!qkv || !out || !lse || S <= 0 || H <= 0) return IQ_ERR_ARG;
+  if (mask_hstride != 0 && mask_hstride != (long)S * S) return IQ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   IQ_PROF(IQ_FAM_ATTN_FWD, st);
-  switch (dh) {
-    case 16: return launch_fwd<16>(qkv, out, lse, B, S, H, st);
-    case 32: return launch_fwd<32>(qkv, out, lse, B, S, H, st);
-    case 64: return launch_fwd<64>(qkv, out, lse, B, S, H, st);
-    default: return IQ_ERR_UNSUPPORTED;
-  }
+  return mask ? dispatch_fwd<true>(qkv, out, lse, mask, mask_hstride, B, S, H, dh, st)
+              : dispatch_fwd<false>(qkv, out, lse, nullptr, 0, B, S, H, dh, st);
+}
+extern "C" int iq_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int dh, iq_stream_t stream) {
+  return iq_attn_fwd_masked(qkv, out, lse, nullptr, 0, B, S, H, dh, stream);
 }
 
-extern "C" int iq_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
-                           int S, int H, int dh, iq_stream_t stream) {
+extern "C" int iq_attn_bwd_masked(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                                  const uint8_t* mask, long mask_hstride, int B, int S, int H, int dh,
+                                  iq_stream_t stream) {
   if (B <= 0) return IQ_OK;
   if (!qkv || !out || !dout || !lse || !dqkv || S <= 0 || H <= 0) return IQ_ERR_ARG;
+  if (mask_hstride != 0 && mask_hstride != (long)S * S) return IQ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   IQ_PROF(IQ_FAM_ATTN_BWD, st);
-  switch (dh) {
-    case 16: return launch_bwd<16>(qkv, out, dout, lse, dqkv, B, S, H, st);
-    case 32: return launch_bwd<32>(qkv, out, dout, lse, dqkv, B, S, H, st);
-    case 64: return launch_bwd<64>(qkv, out, dout, lse, dqkv, B, S, H, st);
-    default: return IQ_ERR_UNSUPPORTED;
-  }
+  return mask ? dispatch_bwd<true>(qkv, out, dout, lse, dqkv, mask, mask_hstride, B, S, H, dh, st)
+              : dispatch_bwd<false>(qkv, out, dout, lse, dqkv, nullptr, 0, B, S, H, dh, st);
+}
+extern "C" int iq_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
+                           int S, int H, int dh, iq_stream_t stream) {
+  return iq_attn_bwd_masked(qkv, out, dout, lse, dqkv, nullptr, 0, B, S, H, dh, stream);
 }

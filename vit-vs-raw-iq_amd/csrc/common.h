@@ -1,5 +1,5 @@
 // Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
-// wave = 64 lanes; bf16 storage, fp32 math; Philox4x32-10 counter RNG for dropout.
+// wave = 64 lanes; bf16 storage, fp32 math; Philox4x32-7 counter RNG for dropout (IQ_PHILOX_ROUNDS below).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -16,8 +16,6 @@
 // ds_read_b128 fragment reads (16 rows x one chunk column per lane group) bank-conflict free.
 // Epilogue: register-only (see gemm_epilogue): C^T accumulators + v_permlane16_swap give each lane 8
 // consecutive columns of a row.
-#include <stdlib.h>
-
 #include "common.h"
 #include "gemm_common.h"
 #include "iqvit.h"
@@ -313,9 +311,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
 
 }  // namespace
 
-int iq_gemm_ws_try_launch(const GemmParams& p, int epi_mode, hipStream_t st);   // gemm_ws.hip
-int iq_gemm_wp_try_launch(const GemmParams& p, int epi_mode, hipStream_t st);   // gemm_wp.hip
-
 #ifdef IQ_GEMM_STAMPS
 static unsigned long long* g_stamps = nullptr;
 extern "C" void iq_debug_set_stamps(unsigned long long* p) { g_stamps = p; }
@@ -349,29 +344,21 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   }
   hipStream_t st = (hipStream_t)stream;
   IQ_PROF(IQ_FAM_GEMM_NT, st);
-  static const int bm_env = getenv("IQ_GEMM_BM") ? atoi(getenv("IQ_GEMM_BM")) : 0;
-  static const bool force_reg = getenv("IQ_GEMM_FORCE_REG") != nullptr;   // diagnostics: register-staged path
-  const bool async_ok = !force_reg && (K % 32 == 0) && (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
-  // Column tile: 192 when it divides N (ViT-Tiny: 192, 576, 768 -- fewer re-reads of the A rows and of the
-  // weight tile per output byte), else 128 for wide N, else 64.  IQ_GEMM_BN=64|128 overrides (diagnostics).
-  static const int bn_env = getenv("IQ_GEMM_BN") ? atoi(getenv("IQ_GEMM_BN")) : 0;
+  const bool async_ok = (K % 32 == 0) && (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
+  // Column tile: 128 for wide N, else 64 (the register-staged fallback for K % 32 != 0 uses the same choice).
   const bool wide = (N % 128 == 0 || N > 512);
-  int bn = wide ? 128 : 64;
-  if (bn_env == 192 && N % 192 == 0 && async_ok) bn = 192;
-  if (bn_env == 64 || bn_env == 128) bn = (bn_env == 128 && !wide) ? 64 : bn_env;
-  const int bm = (async_ok && bm_env == 64) ? 64 : BM;
+  const int bn = wide ? 128 : 64;
+  const int bm = BM;
   p.tiles_m = (M + bm - 1) / bm;
   p.tiles_n = (N + bn - 1) / bn;
   const int grid = p.tiles_m * p.tiles_n;
   int epi_mode = (p.residual ? EPI_RES : 0) | (p.gate ? EPI_GATE : 0) | ((p.pe || p.tok > 0) ? EPI_PE : 0);
   if ((epi_mode & EPI_PE) && (!p.pe || p.tok <= 0 || (epi_mode & (EPI_RES | EPI_GATE)))) return IQ_ERR_UNSUPPORTED;
   if (p.bias && ((uintptr_t)p.bias % 16)) return IQ_ERR_ARG;
-  static const int stagger = getenv("IQ_GEMM_STAGGER") ? atoi(getenv("IQ_GEMM_STAGGER")) : 2;   // measured best of {0,2,6}
-  p.stagger = stagger;
-  // C = A W^T + R, nothing else in the tail, whole rows in one 192-column tile: residual streamed as extra K stages.
+  p.stagger = 2;      // measured best of {0, 2, 6} (profiles/r01_probes.txt)
+  // C = A W^T + R, nothing else in the tail, whole rows in one 192- / 128-column tile: residual streamed as extra K stages.
   // (the plain 192-column tile reads A once -- N=192 K=768: 27.6 vs 37.3 us -- but lost it all to an exposed residual fetch)
-  static const bool no_resk = getenv("IQ_GEMM_NO_RESK") != nullptr;
-  if (!no_resk && async_ok && epi_mode == EPI_RES && (N == 192 || N == 128) && K >= 384 && !p.bias && !p.relu && !p.drop_on &&
+  if (async_ok && epi_mode == EPI_RES && (N == 192 || N == 128) && K >= 384 && !p.bias && !p.relu && !p.drop_on &&
       ((uintptr_t)p.residual % 16) == 0) {
     p.tiles_m = (M + BM - 1) / BM;
     p.tiles_n = 1;
@@ -380,21 +367,14 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
     else gemm_nt_async_kernel<128, 128, EPI_RES, true><<<p.tiles_m, GEMM_THREADS, lds, st>>>(p);
     return iq_launch_status();
   }
-  // The weight-stationary persistent kernel (gemm_ws.hip) is correct but measured 5-25 % SLOWER than the tiled
-  // kernels on the ViT-Tiny shapes (one 8-wave workgroup per CU serialises its own phases): opt-in only.
-  // Wide-N, K <= 192: wave-private kernel with the weight block in registers (gemm_wp.hip); measured equal to the
-  // tiled kernel (see its header), so opt-in: IQ_GEMM_WP=1.
-  static const bool use_wp = getenv("IQ_GEMM_WP") != nullptr;
-  if (use_wp && !force_reg && iq_gemm_wp_try_launch(p, epi_mode, st) == IQ_OK) return iq_launch_status();
-  static const bool use_ws = getenv("IQ_GEMM_WS") != nullptr;
-  if (use_ws && !force_reg && iq_gemm_ws_try_launch(p, epi_mode, st) == IQ_OK) return iq_launch_status();
+  // Variants that were measured and not kept (weight-stationary persistent workgroups, wave-private weight-in-registers
+  // waves, 64- / 256-row tiles, 192-column tiles with epilogue loads) live in scripts/dbg/variants/ with their numbers.
   const size_t lds_async = (size_t)3 * (bm + bn) * 32 * 2;     // ring of 3 stages
   const size_t lds_reg = (size_t)(BM + bn) * BK * 2;
 #define IQ_GEMM_LAUNCH(BN_, EPI_)                                                                  \
   do {                                                                                             \
-    if (async_ok && bm == 64) gemm_nt_async_kernel<64, BN_, EPI_><<<grid, GEMM_THREADS, lds_async, st>>>(p);   \
-    else if (async_ok) gemm_nt_async_kernel<128, BN_, EPI_><<<grid, GEMM_THREADS, lds_async, st>>>(p);       \
-    else gemm_nt_kernel<(BN_ == 192 ? 128 : BN_), EPI_><<<grid, GEMM_THREADS, lds_reg, st>>>(p);   \
+    if (async_ok) gemm_nt_async_kernel<128, BN_, EPI_><<<grid, GEMM_THREADS, lds_async, st>>>(p);  \
+    else gemm_nt_kernel<BN_, EPI_><<<grid, GEMM_THREADS, lds_reg, st>>>(p);                        \
   } while (0)
 #define IQ_GEMM_EPI(BN_)                                                       \
   switch (epi_mode) {                                                          \
@@ -405,7 +385,7 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
     case EPI_PE: IQ_GEMM_LAUNCH(BN_, EPI_PE); break;                           \
     default: return IQ_ERR_UNSUPPORTED;                                        \
   }
-  if (bn == 192) { IQ_GEMM_EPI(192) } else if (bn == 128) { IQ_GEMM_EPI(128) } else { IQ_GEMM_EPI(64) }
+  if (bn == 128) { IQ_GEMM_EPI(128) } else { IQ_GEMM_EPI(64) }
 #undef IQ_GEMM_EPI
 #undef IQ_GEMM_LAUNCH
   return iq_launch_status();

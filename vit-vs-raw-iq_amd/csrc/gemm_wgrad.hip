@@ -429,8 +429,7 @@ struct WgradPlan { int tk, mc, tiles_n, tiles_k, splits, rows_per_split; };
 inline WgradPlan wgrad_plan(int M, int N, int K) {
   WgradPlan w;
   w.tk = (K % 128 == 0 || K > 512) ? 128 : 64;
-  static const int mc_env = getenv("IQ_WGRAD_MC") ? atoi(getenv("IQ_WGRAD_MC")) : 0;   // diagnostic override
-  w.mc = mc_env == 128 ? 128 : 64;      // 128 measured equal on cfg B and spills 5 VGPRs in the 128x128 variant
+  w.mc = 64;      // 128-row stages measured equal on cfg B and spill 5 VGPRs in the 128x128 variant
   const int MC = w.mc;
   w.tiles_n = (N + TN - 1) / TN;
   w.tiles_k = (K + w.tk - 1) / w.tk;
@@ -448,11 +447,8 @@ inline WgradPlan wgrad_plan(int M, int N, int K) {
 }
 
 // Wave-private 64x64 tiles while the outputs are small (operand re-reads grow as N*K/32 per row and stay in L2);
-// the shared 128x128 tiles for the large, MFMA-bound shapes (ViT-Base).  IQ_WGRAD_KERNEL=shared|pw overrides.
-inline bool pw_eligible(int N, int K) {
-  static const char* force = getenv("IQ_WGRAD_KERNEL");
-  return force ? (force[0] == 'p') : ((long)N * K <= 512 * 1024);
-}
+// the shared 128x128 tiles for the large, MFMA-bound shapes (ViT-Base).
+inline bool pw_eligible(int N, int K) { return (long)N * K <= 512 * 1024; }
 inline size_t pad4(size_t v) { return (v + 3) / 4 * 4; }
 
 struct PwPlan { int ntile, splits, rows_per_split; size_t floats; };
@@ -515,8 +511,8 @@ int wgrad_shared_one(const iq_wgrad_problem_t& pb, int M, float* ws, int accumul
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     k<<<grid, WG_THREADS, lds, st>>>(q);                                                                         \
   } while (0)
-  if (w.tk == 128) { if (w.mc == 128) IQ_WG_LAUNCH(128, 128); else IQ_WG_LAUNCH(128, 64); }
-  else { if (w.mc == 128) IQ_WG_LAUNCH(64, 128); else IQ_WG_LAUNCH(64, 64); }
+  if (w.tk == 128) IQ_WG_LAUNCH(128, 64);
+  else IQ_WG_LAUNCH(64, 64);
 #undef IQ_WG_LAUNCH
   RedGroup rg;
   memset(&rg, 0, sizeof(rg));

@@ -225,14 +225,17 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
     const float lse = mx + logf(se);
     float sum_logp = 0.f;
     for (int k = 0; k < K; ++k) sum_logp += z[k] - lse;
-    const float nll = -(z[y] - lse);
+    // a label outside [0, K) (torch raises a device-side assert): never read out of bounds; the frame's loss and
+    // gradient become NaN so the mistake is loud without taking the GPU context down
+    const bool y_ok = y >= 0 && y < K;
+    const float nll = y_ok ? -(z[y] - lse) : __builtin_nanf("");
     lacc += (1.0f - smoothing) * nll + smoothing * (-sum_logp / (float)K);
     cacc += (am == y) ? 1 : 0;
     if (dlogits) {
       for (int k = 0; k < K; ++k) {
         const float pk = expf(z[k] - lse);
         const float tgt = (k == y ? 1.0f - smoothing : 0.f) + smoothing / (float)K;
-        dlogits[(long)b * K + k] = (pk - tgt) / denom;
+        dlogits[(long)b * K + k] = y_ok ? (pk - tgt) / denom : __builtin_nanf("");
       }
     }
   }

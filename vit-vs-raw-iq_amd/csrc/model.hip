@@ -16,7 +16,6 @@
 //   every optimizer step), fp32 MFMA accumulation.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
-#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -43,21 +42,13 @@ struct LayerOff {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// Workgroup budget of a layer's grouped weight-gradient launch when it runs on the side stream next to the following
-// layer's dX chain (0 = no overlap: same stream, whole GPU).  IQ_BWD_OVERLAP=<workgroups> overrides.
-inline int bwd_overlap_budget() {
-  static const int v = getenv("IQ_BWD_OVERLAP") ? atoi(getenv("IQ_BWD_OVERLAP")) : 0;
-  return v < 0 ? 0 : v;
-}
-
 struct WsPlan {
   size_t step_ctr, patches, x0, head_feat, head_stat;
   struct L { size_t qkv, att, lse, z1, mean1, rstd1, x1, hid, z2, mean2, rstd2, x2; };
   std::vector<L> layers;
-  size_t gA, gB, gAtt, demb, wgrad_ws, wgrad_ws_bytes, ln_part[2][2], embw_scratch;
-  // dY operands of a layer's weight gradients: two sets (layer parity), so the gradients of layer l can still read
-  // theirs on the side stream while layer l-1's dX chain fills the other set
-  size_t gZ[2], gY[2], gZ1[2], gY1[2], gH[2], gQKV[2];
+  size_t gA, gB, gAtt, demb, wgrad_ws, wgrad_ws_bytes, ln_part[2], embw_scratch;
+  // dY operands of a layer's weight gradients (live from their producer to the layer's grouped weight-gradient launch)
+  size_t gZ, gY, gZ1, gY1, gH, gQKV;
   size_t total;
 };
 
@@ -152,9 +143,7 @@ struct iq_model {
   const float* pe = nullptr;
   unsigned char* shadow = nullptr;
   std::string err;
-  // side stream + events for the overlapped weight gradients (created at bind)
-  hipStream_t side = nullptr;
-  hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+  uint32_t* step_ctr = nullptr;   // caller-owned persistent device counter of the dropout step (iq_model_bind_step_counter)
   uint64_t last_seed = 0;   // seed of the last training forward; backward regenerates the same masks
   bool last_tr = false;     // whether the last forward applied dropout
 
@@ -213,14 +202,12 @@ WsPlan plan_ws(const iq_model* m, int B) {
   }
   w.gA = take(M * D * 2);
   w.gB = take(M * D * 2);
-  for (int par = 0; par < 2; ++par) {
-    w.gZ[par] = take(M * D * 2);
-    w.gY[par] = take(M * D * 2);
-    w.gZ1[par] = take(M * D * 2);
-    w.gY1[par] = take(M * D * 2);
-    w.gH[par] = take(M * F * 2);
-    w.gQKV[par] = take(M * 3 * D * 2);
-  }
+  w.gZ = take(M * D * 2);
+  w.gY = take(M * D * 2);
+  w.gZ1 = take(M * D * 2);
+  w.gY1 = take(M * D * 2);
+  w.gH = take(M * F * 2);
+  w.gQKV = take(M * 3 * D * 2);
   w.gAtt = take(M * D * 2);
   w.demb = take(MT * D * 2);
   size_t wb = 0;
@@ -234,13 +221,11 @@ WsPlan plan_ws(const iq_model* m, int B) {
     g[3].N = (int)(3 * D); g[3].K = (int)D;
     mx(iq_wgrad_grouped_ws_bytes(g, 4, (int)M, 0));
     for (int k = 0; k < 4; ++k) mx(iq_wgrad_grouped_ws_bytes(g + k, 1, (int)M, 0));
-    mx(iq_wgrad_grouped_ws_bytes(g, 4, (int)M, bwd_overlap_budget()));
   }
   mx(iq_wgrad_ws_bytes((int)MT, (int)D, m->Ppad));
   w.wgrad_ws_bytes = wb;
   w.wgrad_ws = take(wb);
-  for (int par = 0; par < 2; ++par)           // per layer parity: norm2 / norm1 partial rows, reduced with the layer's slabs
-    for (int k = 0; k < 2; ++k) w.ln_part[par][k] = take(iq_ln_bwd_ws_bytes((int)D));
+  for (int k = 0; k < 2; ++k) w.ln_part[k] = take(iq_ln_bwd_ws_bytes((int)D));   // norm2 / norm1 partial rows, reduced with the layer's slabs
   w.embw_scratch = take((size_t)D * m->Ppad * 4 + 256);
   w.total = cur;
   return w;
@@ -373,10 +358,6 @@ extern "C" int iq_model_create(const iq_model_cfg_t* cfg, iq_model_t** out) {
 
 extern "C" void iq_model_destroy(iq_model_t* m) {
   if (!m) return;
-  if (m->side) {
-    (void)hipStreamDestroy(m->side);
-    for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(m->ev_ready[i]); (void)hipEventDestroy(m->ev_done[i]); }
-  }
   delete m;
 }
 extern "C" const char* iq_model_last_error(const iq_model_t* m) { return m ? m->err.c_str() : "null model"; }
@@ -405,20 +386,19 @@ extern "C" int iq_model_bind(iq_model_t* m, float* params, float* grads, const f
   if (!params || !pe || !shadow) return fail(m, IQ_ERR_ARG, "bind: params, pe and shadow are required");
   if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)shadow) & 255) return fail(m, IQ_ERR_ARG, "bind: buffers must be 256 B aligned");
   m->params = params; m->grads = grads; m->pe = pe; m->shadow = (unsigned char*)shadow;
-  if (!m->side && bwd_overlap_budget() > 0) {
-    bool ok = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i < 2; ++i) {
-      ok = ok && hipEventCreateWithFlags(&m->ev_ready[i], hipEventDisableTiming) == hipSuccess;
-      ok = ok && hipEventCreateWithFlags(&m->ev_done[i], hipEventDisableTiming) == hipSuccess;
-    }
-    if (!ok) return fail(m, IQ_ERR_LAUNCH, "bind: creating the side stream / events failed");
-  }
   if (m->table_uploaded_to != shadow && !m->ttab.empty()) {
     // one small synchronous copy per (re)binding of the shadow buffer; never on the step path
     if (hipMemcpy(m->shadow + m->sh_table, m->ttab.data(), m->ttab.size() * sizeof(TransDesc), hipMemcpyHostToDevice) != hipSuccess)
       return fail(m, IQ_ERR_LAUNCH, "bind: uploading the transpose table failed");
     m->table_uploaded_to = shadow;
   }
+  return IQ_OK;
+}
+
+extern "C" int iq_model_bind_step_counter(iq_model_t* m, uint32_t* counter) {
+  if (!m) return IQ_ERR_ARG;
+  if ((uintptr_t)counter & 3) return fail(m, IQ_ERR_ARG, "bind_step_counter: counter must be 4 B aligned");
+  m->step_ctr = counter;
   return IQ_OK;
 }
 
@@ -455,7 +435,9 @@ extern "C" int iq_model_forward(iq_model_t* m, const float* src, int batch, void
   const int D = c.d_model, F = c.ffn_hidden, S = m->S, H = c.n_head, B = batch;
   const int M = B * S, MT = B * m->tok;
   const bool tr = training != 0 && c.drop_prob > 0.f;
-  uint32_t* step_dev = (uint32_t*)(ws + w.step_ctr);
+  // dropout step: the caller's persistent counter when bound (survives workspace reallocation, starts from a defined
+  // value), else a slot of the workspace
+  uint32_t* step_dev = m->step_ctr ? m->step_ctr : (uint32_t*)(ws + w.step_ctr);
   m->last_tr = tr;
   if (tr) {
     set_u32_kernel<<<1, 64, 0, st>>>(step_dev, step, step == 0xFFFFFFFFu ? 1 : 0);
@@ -535,7 +517,7 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
   const int D = c.d_model, F = c.ffn_hidden, S = m->S, H = c.n_head, B = batch, K = c.num_classes;
   const int M = B * S, MT = B * m->tok;
   const bool tr = m->last_tr;   // masks are regenerated only if the forward in this workspace applied them
-  const uint32_t* step_dev = (const uint32_t*)(ws + w.step_ctr);
+  const uint32_t* step_dev = m->step_ctr ? m->step_ctr : (const uint32_t*)(ws + w.step_ctr);
   const float* P = m->params;
   float* G = m->grads;
   float* wws = (float*)(ws + w.wgrad_ws);
@@ -554,32 +536,23 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
     if (denc) f32_into_bf16_kernel<<<blocks_for((size_t)M * D / 8), 256, 0, st>>>(denc, (bf16*)(ws + w.gA), (size_t)M * D / 8, dlogits ? 1 : 0);
   }
   // The four weight gradients of a layer are independent of its dX chain and of each other, and their dY operands
-  // (gY|gZ, gH, gY1|gZ1, gQKV) all stay live until the chain of the layer two below overwrites them: they run as ONE
-  // grouped launch (+ one slab reduce) instead of four (+ four) -- one pipeline fill / drain, 3x fewer slab bytes.
-  // With a workgroup budget (bwd_overlap_budget) that launch goes to the side stream as soon as the layer's last dY
-  // exists and shares the CUs with the next layer's chain; every call joins the side stream before it returns.
-  const int budget = m->side ? bwd_overlap_budget() : 0;
-  bool pending[2] = {false, false};
+  // (gY|gZ, gH, gY1|gZ1, gQKV) all stay live until the end of the layer: they run as ONE grouped launch (+ one slab
+  // reduce) instead of four (+ four) -- one pipeline fill / drain, 3x fewer slab bytes.  (Measured and not kept, see
+  // profiles/r01_probes.txt: the launch on a side stream with a workgroup budget next to the following layer's chain
+  // 6.57-7.29 vs 6.58 ms/step; each weight gradient right after its data-gradient GEMM 6.35 vs 6.15-6.22; the FFN
+  // data-gradient pair as one chained launch 6.65-6.68 vs 6.62-6.64.)
   for (int sidx = (stage_hi > Lr ? Lr : stage_hi); sidx >= 1 && sidx >= stage_lo; --sidx) {
-    const int l = sidx - 1, par = l & 1;
+    const int l = sidx - 1;
     const LayerOff& o = m->L[l];
     const WsPlan::L& a = w.layers[l];
     const unsigned char* xin = l == 0 ? ws + w.x0 : ws + w.layers[l - 1].x2;
-    unsigned char *gZ = ws + w.gZ[par], *gY = ws + w.gY[par], *gZ1 = ws + w.gZ1[par], *gY1 = ws + w.gY1[par];
-    unsigned char *gH = ws + w.gH[par], *gQKV = ws + w.gQKV[par];
-    if (pending[par]) {                              // the gradients of layer l+2 still read this buffer set
-      (void)hipStreamWaitEvent(st, m->ev_done[par], 0);
-      pending[par] = false;
-    }
+    unsigned char *gZ = ws + w.gZ, *gY = ws + w.gY, *gZ1 = ws + w.gZ1, *gY1 = ws + w.gY1;
+    unsigned char *gH = ws + w.gH, *gQKV = ws + w.gQKV;
     iq_epilogue_t e;
-    // IQ_WGRAD_UNGROUPED=1 (experiment, measured 6.35 vs 6.15-6.22 ms/step, i.e. worse): each weight gradient right
-    // after the data-gradient GEMM that read the same dY, while that operand is still in the 256 MB Infinity Cache,
-    // instead of one grouped launch at the end of the layer
-    static const bool ungrouped = getenv("IQ_WGRAD_UNGROUPED") != nullptr;
     // norm2 backward (+ regenerated dropout2 mask)
     const iq_dropout_t dr2 = m->bwd_site(3 + 3 * l, step_dev, tr);
-    float* lp2 = (float*)(ws + w.ln_part[par][0]);
-    float* lp1 = (float*)(ws + w.ln_part[par][1]);
+    float* lp2 = (float*)(ws + w.ln_part[0]);
+    float* lp1 = (float*)(ws + w.ln_part[1]);
     IQ_TRY(iq_ln_bwd(ws + w.gA, ws + a.z2, (const float*)(ws + a.mean2), (const float*)(ws + a.rstd2), P + o.g2,
                      gZ, gY, &dr2, nullptr, nullptr, lp2, accumulate, M, D, stream), "norm2 bwd");
     const unsigned char* dO2 = tr ? gY : gZ;
@@ -593,51 +566,23 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
     const int lrows = iq_ln_bwd_partial_rows(M, D);
     const iq_reduce_seg_t lnseg[4] = {{lp2, lrows, 2L * D, G + o.g2, D}, {lp2 + D, lrows, 2L * D, G + o.be2, D},
                                       {lp1, lrows, 2L * D, G + o.g1, D}, {lp1 + D, lrows, 2L * D, G + o.be1, D}};
-    auto one_wgrad = [&](int k, bool with_ln) {
-      return iq_gemm_bf16_wgrad_grouped(wg + k, 1, M, wws, w.wgrad_ws_bytes, accumulate, 0, with_ln ? lnseg : nullptr,
-                                        with_ln ? 4 : 0, stream);
-    };
     memset(&e, 0, sizeof(e));
     e.gate = ws + a.hid; e.ldg = F; e.gate_scale = dscale;
-    iq_epilogue_t e2;
-    memset(&e2, 0, sizeof(e2));
-    e2.residual = gZ; e2.ldr = D;
-    // FFN data-gradient chain in one launch (iq_gemm_bf16_chain, bit-identical to the two GEMMs): 71.7 vs 78.9 us in
-    // isolation on cfg B, but no gain inside the step (6.65-6.68 vs 6.62-6.64 ms) -- opt-in, IQ_BWD_CHAIN=1.
-    static const bool use_chain = getenv("IQ_BWD_CHAIN") != nullptr;
-    if (use_chain && iq_gemm_chain_supported(D, F) && M >= 64 * 256) {
-      IQ_TRY(iq_gemm_bf16_chain(dO2, D, m->sht(o.t_w2), D, gH, F, m->sht(o.t_w1), F, ws + w.gB, D, M, F, D, &e, &e2, stream),
-             "ffn dgrad chain");
-    } else {
-      IQ_TRY(iq_gemm_bf16_nt(dO2, D, m->sht(o.t_w2), D, gH, F, M, F, D, &e, stream), "ffn2 dgrad");
-      if (ungrouped) IQ_TRY(one_wgrad(0, false), "ffn2 wgrad");
-      IQ_TRY(iq_gemm_bf16_nt(gH, F, m->sht(o.t_w1), F, ws + w.gB, D, M, D, F, &e2, stream), "ffn1 dgrad");
-      if (ungrouped) IQ_TRY(one_wgrad(1, false), "ffn1 wgrad");
-    }
+    IQ_TRY(iq_gemm_bf16_nt(dO2, D, m->sht(o.t_w2), D, gH, F, M, F, D, &e, stream), "ffn2 dgrad");
+    memset(&e, 0, sizeof(e));
+    e.residual = gZ; e.ldr = D;
+    IQ_TRY(iq_gemm_bf16_nt(gH, F, m->sht(o.t_w1), F, ws + w.gB, D, M, D, F, &e, stream), "ffn1 dgrad");
     // norm1 backward (+ dropout1 mask)
     const iq_dropout_t dr1 = m->bwd_site(1 + 3 * l, step_dev, tr);
     IQ_TRY(iq_ln_bwd(ws + w.gB, ws + a.z1, (const float*)(ws + a.mean1), (const float*)(ws + a.rstd1), P + o.g1,
                      gZ1, gY1, &dr1, nullptr, nullptr, lp1, accumulate, M, D, stream), "norm1 bwd");
     IQ_TRY(iq_gemm_bf16_nt(dAo, D, m->sht(o.t_wo), D, ws + w.gAtt, D, M, D, D, nullptr, stream), "out-proj dgrad");
-    if (ungrouped) IQ_TRY(one_wgrad(2, false), "out-proj wgrad");
     IQ_TRY(iq_attn_bwd(ws + a.qkv, ws + a.att, ws + w.gAtt, (const float*)(ws + a.lse), gQKV, B, S, H, m->dh, stream), "attention bwd");
-    if (budget > 0) {
-      (void)hipEventRecord(m->ev_ready[par], st);
-      (void)hipStreamWaitEvent(m->side, m->ev_ready[par], 0);
-      IQ_TRY(iq_gemm_bf16_wgrad_grouped(wg, 4, M, wws, w.wgrad_ws_bytes, accumulate, budget, lnseg, 4, (iq_stream_t)m->side),
-             "layer weight gradients (side stream)");
-      (void)hipEventRecord(m->ev_done[par], m->side);
-      pending[par] = true;
-    }
     memset(&e, 0, sizeof(e));
     e.residual = gZ1; e.ldr = D;
     IQ_TRY(iq_gemm_bf16_nt(gQKV, 3 * D, m->sht(o.t_wqkv), 3 * D, ws + w.gA, D, M, D, 3 * D, &e, stream), "qkv dgrad");
-    if (ungrouped) IQ_TRY(one_wgrad(3, true), "qkv wgrad");
-    else if (budget <= 0)
-      IQ_TRY(iq_gemm_bf16_wgrad_grouped(wg, 4, M, wws, w.wgrad_ws_bytes, accumulate, 0, lnseg, 4, stream), "layer weight gradients");
+    IQ_TRY(iq_gemm_bf16_wgrad_grouped(wg, 4, M, wws, w.wgrad_ws_bytes, accumulate, 0, lnseg, 4, stream), "layer weight gradients");
   }
-  for (int par = 0; par < 2; ++par)
-    if (pending[par]) (void)hipStreamWaitEvent(st, m->ev_done[par], 0);
   if (stage_lo == 0) {
     const iq_dropout_t dr0 = m->bwd_site(0, step_dev, tr);
     IQ_TRY(iq_embed_bwd_gather(ws + w.gA, ws + w.demb, m->has_cls ? G + m->cls : nullptr, B, S, m->tok, D, m->has_cls,

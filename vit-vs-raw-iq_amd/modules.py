@@ -13,7 +13,13 @@ load_state_dict and .to() behave as in the reference).  The arithmetic does not 
 AMCTransformer.forward / Encoder.forward hand the whole forward (and, through one
 autograd.Function, the whole backward) to the native runtime in csrc/model.hip.  On first use on a
 GPU the parameters are re-homed as views of one flat fp32 HBM buffer whose layout the native side
-defines; nothing else about them changes.
+defines; nothing else about them changes.  A model and its encoder share ONE plan (one flat buffer):
+`model.encoder(x)` runs the model's plan up to the encoder output.
+
+The leaf layers (LayerNorm, MultiHeadAttention, PositionwiseFeedForward, EncoderLayer, the embeddings)
+also run on their own -- forward hooks, per-layer feature extraction -- through the per-op C ABI
+(functional.py: iq_ln_*, iq_gemm_bf16_*, iq_attn_*), with autograd; they are the reference's layer
+bodies (V/models/blocks/encoder_layer.py:18-35 etc.) over native ops.  Training runs the plan, not these.
 
 There is no CPU path: a CPU tensor raises.  The CPU restatement lives in oracle/ (tests only).
 """
@@ -28,21 +34,14 @@ import torch
 from torch import nn
 
 from . import _native as N
-
-_NO_PER_LAYER = ("{name}.forward is not a separate native entry point: run the enclosing Encoder / AMCTransformer "
-                 "(the MI355X path executes the whole encoder as one native plan; per-layer entry points are the "
-                 "C ABI in include/iqvit.h).")
-
-
-class _ShellMixin:
-    def _refuse(self):
-        raise NotImplementedError(_NO_PER_LAYER.format(name=type(self).__name__))
+from . import functional as NF
 
 
 # ------------------------------------------------------------------------------------------------
-# leaf shells (parameters only; same attribute names as the reference)
+# leaf layers: same attribute names as the reference (hence state_dict keys); each forward is the
+# reference's layer body over the native per-op entry points (functional.py)
 # ------------------------------------------------------------------------------------------------
-class LayerNorm(nn.Module, _ShellMixin):
+class LayerNorm(nn.Module):
     """layers_norm.py:4-19 -- params are `gamma` / `beta`, eps 1e-12."""
 
     def __init__(self, d_model, eps=1e-12):
@@ -52,17 +51,22 @@ class LayerNorm(nn.Module, _ShellMixin):
         self.eps = eps
 
     def forward(self, x):
-        self._refuse()
+        return NF.layer_norm(x, self.gamma, self.beta, self.eps)
 
 
-class ScaleDotProductAttention(nn.Module, _ShellMixin):
-    """scale_dot_product_attention.py:5-39 (no parameters)."""
+class ScaleDotProductAttention(nn.Module):
+    """scale_dot_product_attention.py:5-39 (no parameters): softmax(q k^T / sqrt(dh)) v on (B, H, S, dh) tensors,
+    optional mask (mask == 0 -> score -10000, :30-31).  Returns (v, score) like the reference; the fused kernel never
+    forms `score`, so it is rebuilt with a plain softmax only when asked for (`need_score`, default as the reference;
+    MultiHeadAttention discards it, multi_head_attention.py:24, and passes need_score=False)."""
 
-    def forward(self, q, k, v, mask=None, e=1e-12):
-        self._refuse()
+    def forward(self, q, k, v, mask=None, e=1e-12, need_score=True):
+        out = NF.attention(q, k, v, mask)
+        score = NF.attention_probabilities(q, k, mask) if need_score else None
+        return out, score
 
 
-class MultiHeadAttention(nn.Module, _ShellMixin):
+class MultiHeadAttention(nn.Module):
     """multi_head_attention.py:6-47 -- four separate Linear(D,D) with bias."""
 
     def __init__(self, d_model, n_head):
@@ -75,10 +79,27 @@ class MultiHeadAttention(nn.Module, _ShellMixin):
         self.w_concat = nn.Linear(d_model, d_model)
 
     def forward(self, q, k, v, mask=None):
-        self._refuse()
+        q = NF.linear(q, self.w_q.weight, self.w_q.bias)
+        k = NF.linear(k, self.w_k.weight, self.w_k.bias)
+        v = NF.linear(v, self.w_v.weight, self.w_v.bias)
+        q, k, v = self.split(q), self.split(k), self.split(v)
+        out, _ = self.attention(q, k, v, mask=mask, need_score=False)
+        out = self.concat(out)
+        return NF.linear(out, self.w_concat.weight, self.w_concat.bias)
+
+    def split(self, tensor):
+        """(B, L, D) -> (B, H, L, dh)  (multi_head_attention.py:34-40)."""
+        batch_size, length, d_model = tensor.size()
+        d_tensor = d_model // self.n_head
+        return tensor.view(batch_size, length, self.n_head, d_tensor).transpose(1, 2)
+
+    def concat(self, tensor):
+        """inverse of split (multi_head_attention.py:41-47)."""
+        batch_size, head, length, d_tensor = tensor.size()
+        return tensor.transpose(1, 2).contiguous().view(batch_size, length, head * d_tensor)
 
 
-class PositionwiseFeedForward(nn.Module, _ShellMixin):
+class PositionwiseFeedForward(nn.Module):
     """position_wise_feed_forward.py:3-17 -- Linear, ReLU, Dropout, Linear."""
 
     def __init__(self, d_model, hidden, drop_prob=0.1):
@@ -89,10 +110,12 @@ class PositionwiseFeedForward(nn.Module, _ShellMixin):
         self.dropout = nn.Dropout(p=drop_prob)
 
     def forward(self, x):
-        self._refuse()
+        x = NF.linear(x, self.linear1.weight, self.linear1.bias, relu=True)     # linear1 + relu in one epilogue
+        x = self.dropout(x)
+        return NF.linear(x, self.linear2.weight, self.linear2.bias)
 
 
-class EncoderLayer(nn.Module, _ShellMixin):
+class EncoderLayer(nn.Module):
     """encoder_layer.py:7-35 -- post-norm block."""
 
     def __init__(self, d_model, ffn_hidden, n_head, drop_prob):
@@ -104,22 +127,30 @@ class EncoderLayer(nn.Module, _ShellMixin):
         self.norm2 = LayerNorm(d_model=d_model)
         self.dropout2 = nn.Dropout(p=drop_prob)
 
-    def forward(self, x, src_mask):
-        self._refuse()
+    def forward(self, x, src_mask=None):
+        _x = x
+        x = self.attention(q=x, k=x, v=x, mask=src_mask)
+        x = self.dropout1(x)
+        x = self.norm1(x + _x)
+        _x = x
+        x = self.ffn(x)
+        x = self.dropout2(x)
+        return self.norm2(x + _x)
 
 
-class PatchEmbedding(nn.Module, _ShellMixin):
-    """ViT patch_embedding.py:3-15 -- Conv2d(C, D, k=p, s=p)."""
+class PatchEmbedding(nn.Module):
+    """ViT patch_embedding.py:3-15 -- Conv2d(C, D, k=p, s=p), flatten, transpose: (B,C,H,W) -> (B,N,D)."""
 
     def __init__(self, in_channels, patch_size, embedding_dim):
         super().__init__()
         self.projection = nn.Conv2d(in_channels, embedding_dim, kernel_size=patch_size, stride=patch_size)
+        self._patch = patch_size
 
     def forward(self, x):
-        self._refuse()
+        return NF.patch_embed(x, self.projection.weight, self.projection.bias, 0, self._patch)
 
 
-class SequenceEmbedding(nn.Module, _ShellMixin):
+class SequenceEmbedding(nn.Module):
     """rawIQ patch_embedding.py:5-60 -- Conv1d k=1 ('conv1d') or k=s=segment ('segment')."""
 
     def __init__(self, in_channels=2, embedding_dim=256, method="conv1d", segment_size=None):
@@ -138,10 +169,12 @@ class SequenceEmbedding(nn.Module, _ShellMixin):
             raise ValueError(f"Unknown method: {method}. Use 'conv1d' or 'segment'")
 
     def forward(self, x):
-        self._refuse()
+        """(B, C, L) -> (B, L/k, D)  (R/.../patch_embedding.py:47-60)."""
+        k = 1 if self.method == "conv1d" else self.segment_size
+        return NF.patch_embed(x, self.projection.weight, self.projection.bias, 1, k)
 
 
-class PositionalEncodingViT(nn.Module, _ShellMixin):
+class PositionalEncodingViT(nn.Module):
     """ViT positional_encoding.py:4-29: table via pow(10000, 2i/D) then divide; buffer `encoding`."""
 
     def __init__(self, d_model, max_len=5000, device="cpu"):
@@ -155,10 +188,11 @@ class PositionalEncodingViT(nn.Module, _ShellMixin):
         self.register_buffer("encoding", enc)
 
     def forward(self, x):
-        self._refuse()
+        """x + encoding[:S]  (V/.../positional_encoding.py:21-29)."""
+        return x + self.encoding[: x.size(1), :].unsqueeze(0)
 
 
-class PositionalEncodingRawIQ(nn.Module, _ShellMixin):
+class PositionalEncodingRawIQ(nn.Module):
     """rawIQ positional_encoding.py:6-82: table via exp(-ln(1e4) 2i/D) then multiply."""
 
     def __init__(self, d_model, max_len=5000, device="cpu", dropout=0.0):
@@ -172,15 +206,22 @@ class PositionalEncodingRawIQ(nn.Module, _ShellMixin):
         self.dropout = nn.Dropout(p=dropout) if dropout > 0 else None
 
     def forward(self, x):
-        self._refuse()
+        """R/.../positional_encoding.py:55-82."""
+        seq_len = x.size(1)
+        if seq_len > self.encoding.size(0):
+            raise ValueError(f"Sequence length {seq_len} exceeds maximum length {self.encoding.size(0)}. "
+                             "Increase max_len parameter.")
+        x = x + self.encoding[:seq_len, :].unsqueeze(0)
+        return self.dropout(x) if self.dropout is not None else x
 
 
 # ------------------------------------------------------------------------------------------------
 # native runner: flat parameter storage + workspace + calls into libiqvit.so
 # ------------------------------------------------------------------------------------------------
 class NativePlan:
-    """One iq_model_t plus the HBM buffers it is bound to.  Owned by an AMCTransformer or a
-    stand-alone Encoder."""
+    """One iq_model_t plus the HBM buffers it is bound to.  Owned by an AMCTransformer (shared with its
+    encoder) or by a stand-alone Encoder."""
+    _count = 0
 
     def __init__(self, owner: nn.Module, cfg: N.ModelCfg, prefix_strip: str = ""):
         self._owner = weakref.ref(owner)
@@ -211,8 +252,13 @@ class NativePlan:
         self.ws_batch = 0
         self.shadow_version = -1
         self.generation = 0          # bumped by every forward that writes the workspace
-        self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        # dropout seed: derived from torch's seed WITHOUT drawing from the global generator (a draw here, at the first
+        # forward, would shift a seeded caller's random stream relative to the reference's)
+        NativePlan._count += 1
+        self.seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + NativePlan._count * 0xD1B54A32D192ED03) & ((1 << 62) - 1)
         self.step = 0
+        self.step_ctr: Optional[torch.Tensor] = None    # persistent device u32: the dropout step the kernels read
+        self.ctr_value = -1                             # host mirror of step_ctr (-1: unknown)
         self._probe = None
 
     def __deepcopy__(self, memo):      # copies of a module build their own plan lazily
@@ -269,6 +315,9 @@ class NativePlan:
         self.shadow = torch.empty(self.L.iq_model_shadow_bytes(self.h), dtype=torch.uint8, device=device)
         self.gflat = None
         self.shadow_version = -1
+        self.step_ctr = torch.zeros(1, dtype=torch.int32, device=device)
+        self.ctr_value = 0
+        N.check(self.L.iq_model_bind_step_counter(self.h, N.ptr(self.step_ctr)), "iq_model_bind_step_counter", self.h)
         self._bind_native(None)
 
     def _bind_native(self, gflat):
@@ -276,10 +325,14 @@ class NativePlan:
                 "iq_model_bind", self.h)
         self.gflat = gflat
 
-    def ensure(self, device: torch.device):
+    def is_bound(self, device=None) -> bool:
+        """True while the owner's parameters are still views of this plan's flat buffer."""
         p = self._probe
-        if (self.flat is None or self.flat.device != device or p is None
-                or p.data.untyped_storage().data_ptr() != self.flat.untyped_storage().data_ptr()):
+        return not (self.flat is None or (device is not None and self.flat.device != device) or p is None
+                    or p.data.untyped_storage().data_ptr() != self.flat.untyped_storage().data_ptr())
+
+    def ensure(self, device: torch.device):
+        if not self.is_bound(device):
             self.bind(device)
         # `p.data = view` does not share version counters with the flat buffer, so sum the parameters'
         # own counters: every in-place update (optimizer step, load_state_dict, p.add_()) bumps one.
@@ -313,6 +366,7 @@ class NativePlan:
         enc = torch.empty(B, self.S, self.cfg.d_model, dtype=torch.float32, device=dev) if want_enc else None
         if training:
             self.step += 1
+            self.ctr_value = self.step & 0x7FFFFFFF     # the forward writes this value into step_ctr
         self.generation += 1
         N.check(self.L.iq_model_forward(self.h, N.ptr(src), B, N.ptr(ws), ws.numel(), 1 if training else 0,
                                         self.seed, self.step & 0x7FFFFFFF, N.ptr(enc), N.ptr(logits),
@@ -391,6 +445,34 @@ def _check_src(src, ndim, what):
     return src.contiguous().float()
 
 
+class _WeakLink:
+    """Weak back-reference from an encoder to the AMCTransformer that owns it.  Copies and pickles carry an empty
+    link; the owner re-links in its constructor / __setstate__ (copy.deepcopy and torch.save of whole modules)."""
+
+    def __init__(self, target=None):
+        self._ref = weakref.ref(target) if target is not None else None
+
+    def __call__(self):
+        return self._ref() if self._ref is not None else None
+
+    def __deepcopy__(self, memo):
+        return _WeakLink()
+
+    def __reduce__(self):
+        return (_WeakLink, ())
+
+
+def _link(parent):
+    object.__setattr__(parent.encoder, "_parent_ref", _WeakLink(parent))
+
+
+def _parent_of(encoder):
+    """The AMCTransformer that owns `encoder`, if it still does."""
+    ref = getattr(encoder, "_parent_ref", None)
+    parent = ref() if ref is not None else None
+    return parent if parent is not None and getattr(parent, "encoder", None) is encoder else None
+
+
 def _run(plan: NativePlan, owner: nn.Module, src, want):
     names, params = [], []
     for n, p in owner.named_parameters():
@@ -429,6 +511,17 @@ class EncoderViT(nn.Module):
     def _cfg(self, num_classes=1):
         return N.ModelCfg(num_classes=num_classes, **self._geom)
 
+    def _forward_layers(self, src, src_mask):
+        """V/models/encoder.py:34-53 layer by layer (the only path that takes a src_mask; no reference caller passes
+        one, so the fused plan has no mask input)."""
+        x = self.patch_embedding(src)
+        cls = self.cls_token.repeat(x.shape[0], 1, 1)
+        x = torch.cat([cls, x], dim=1)
+        x = self.dropout(self.positional_encoding(x))
+        for layer in self.layers:
+            x = layer(x, src_mask)
+        return x
+
     def _expect(self, src):
         g = self._geom
         src = _check_src(src, 4, "(batch, in_channels, img_size_h, img_size_w)")
@@ -439,8 +532,11 @@ class EncoderViT(nn.Module):
 
     def forward(self, src, src_mask=None):
         if src_mask is not None:
-            raise NotImplementedError("src_mask is never passed by any reference caller and is not implemented natively")
+            return self._forward_layers(src, src_mask)
         src = self._expect(src)
+        parent = _parent_of(self)
+        if parent is not None:           # one plan / one flat parameter buffer per model: run the model's plan
+            return _run(parent.native_plan(), parent, src, "enc")
         if self._plan is None:
             self._plan = NativePlan(self, self._cfg(), prefix_strip="encoder.")
         return _run(self._plan, self, src, "enc")
@@ -458,9 +554,15 @@ class AMCTransformerViT(nn.Module):
         self.mlp_head = nn.Linear(d_model, num_classes)
         self._num_classes = num_classes
         self._plan: Optional[NativePlan] = None
+        _link(self)
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        _link(self)
 
     def native_plan(self) -> NativePlan:
         if self._plan is None:
+            _link(self)
             self._plan = NativePlan(self, self.encoder._cfg(self._num_classes))
         return self._plan
 
@@ -509,6 +611,16 @@ class EncoderRawIQ(nn.Module):
     def _cfg(self, num_classes=1):
         return N.ModelCfg(num_classes=num_classes, **self._geom)
 
+    def _forward_layers(self, src, src_mask):
+        """R/models/encoder.py:86-117 layer by layer (the only path that takes a src_mask)."""
+        x = self.sequence_embedding(src)
+        if self.use_cls_token:
+            x = torch.cat([self.cls_token.repeat(x.shape[0], 1, 1), x], dim=1)
+        x = self.dropout(self.positional_encoding(x))
+        for layer in self.layers:
+            x = layer(x, src_mask)
+        return x
+
     def _expect(self, src):
         g = self._geom
         src = _check_src(src, 3, "(batch, in_channels, seq_length)")
@@ -525,8 +637,11 @@ class EncoderRawIQ(nn.Module):
 
     def forward(self, src, src_mask=None):
         if src_mask is not None:
-            raise NotImplementedError("src_mask is never passed by any reference caller and is not implemented natively")
+            return self._forward_layers(src, src_mask)
         src = self._expect(src)
+        parent = _parent_of(self)
+        if parent is not None:           # one plan / one flat parameter buffer per model: run the model's plan
+            return _run(parent.native_plan(), parent, src, "enc")
         if self._plan is None:
             self._plan = NativePlan(self, self._cfg(), prefix_strip="encoder.")
         return _run(self._plan, self, src, "enc")
@@ -556,9 +671,15 @@ class AMCTransformerRawIQ(nn.Module):
         self.mlp_head = nn.Sequential(nn.LayerNorm(d_model), nn.Linear(d_model, num_classes))
         self._num_classes = num_classes
         self._plan: Optional[NativePlan] = None
+        _link(self)
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        _link(self)
 
     def native_plan(self) -> NativePlan:
         if self._plan is None:
+            _link(self)
             self._plan = NativePlan(self, self.encoder._cfg(self._num_classes))
         return self._plan
 

@@ -13,6 +13,8 @@ backward runs in stages (head, layers L-1..0, embedding); after each bucket of s
 corresponding contiguous range of the flat gradient is all-reduced asynchronously while the next
 stages run, and the clip + AdamW kernels wait for all buckets (the clip needs the global-batch
 gradient norm).  Gradient mean = SUM all-reduce, 1/world folded into the norm and AdamW kernels.
+hipGraph replay also works data parallel: the step is captured as one graph per segment between bucket
+boundaries, and the all-reduces are issued between the replays.
 """
 from __future__ import annotations
 
@@ -81,7 +83,7 @@ class FusedTrainer:
 
     def __init__(self, model, lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.99), eps=1e-8, label_smoothing=0.1,
                  max_norm=1.0, device=None, group=None, n_buckets: int = 4, use_graph: bool = False,
-                 dropout_seed: Optional[int] = None):
+                 dropout_seed: Optional[int] = None, sync_params: bool = True):
         self.model = model
         self.device = torch.device(device) if device is not None else next(model.parameters()).device
         if self.device.type != "cuda":
@@ -98,6 +100,8 @@ class FusedTrainer:
         self.plan.seed = (self.plan.seed + 0x9E3779B97F4A7C15 * self.rank) & ((1 << 63) - 1)   # per-rank stream
         with torch.cuda.device(self.device):
             self.plan.ensure(self.device)
+            if self.world > 1 and sync_params:
+                self._sync_parameters()
         n = self.plan.nparam
         d = self.device
         self.gflat = torch.zeros(n, dtype=torch.float32, device=d)
@@ -112,14 +116,33 @@ class FusedTrainer:
         self.steps = 0
         self.buckets = make_buckets(self.plan.cfg.n_layers, n_buckets if self.world > 1 else 1)
         self.ranges = [self.plan.grad_range(hi, lo) for hi, lo in self.buckets]
-        self.use_graph = bool(use_graph) and self.world == 1
-        self._graph = None
+        self.use_graph = bool(use_graph)
+        self._graphs = None          # one hipGraph per segment (see _segments)
+        self._captured = None        # device pointers baked into the captured graphs
         self._static = None
         self._logits = None
         self._dlogits = None
         self._batch = 0
 
     # ------------------------------------------------------------------------------------------
+    def _sync_parameters(self):
+        """Data-parallel start-up: every rank starts from rank 0's parameters, then all ranks check
+        that they hold the same bytes (a rank that constructed an unseeded or differently loaded model would
+        otherwise all-reduce gradients onto different weights and diverge silently).  Also the first collective of
+        the job: a broken RCCL set-up fails here, not in the middle of a step."""
+        plan, g = self.plan, self.reducer.group
+        dist.broadcast(plan.flat, src=dist.get_global_rank(g, 0) if g is not None else 0, group=g)
+        plan.mark_dirty()
+        plan.ensure(self.device)
+        flat = plan.flat.double()
+        sig = torch.stack([flat.sum(), flat.abs().sum(), (flat * flat).sum()])
+        lo, hi = sig.clone(), sig.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=g)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=g)
+        if not torch.equal(lo, hi):
+            raise N.IqError(f"rank {self.rank}: parameters differ across ranks after the start-up broadcast "
+                            f"(checksums {sig.tolist()} vs min {lo.tolist()} / max {hi.tolist()})")
+
     def set_lr(self, lr: float):
         self.lr = float(lr)
         self.dyn[0] = self.lr
@@ -129,39 +152,68 @@ class FusedTrainer:
             K = self.plan.cfg.num_classes
             self._logits = torch.empty(B, K, dtype=torch.float32, device=self.device)
             self._dlogits = torch.empty(B, K, dtype=torch.float32, device=self.device)
-            self.plan.workspace(B, self.device)
             self._batch = B
-            self._graph = None
+        # every call: an inference forward with a larger batch (evaluate(), model(x)) may have replaced the workspace
+        self.plan.workspace(B, self.device)
 
-    def _launch(self, x: torch.Tensor, y: torch.Tensor, auto_step: bool):
-        """Issue one whole training step on the current stream (capture-safe: no alloc, no sync)."""
-        plan, L, st = self.plan, self.L, N.stream_handle()
+    def _pointers(self):
+        p = self.plan
+        return (p.ws.data_ptr(), p.ws.numel(), p.flat.data_ptr(), p.shadow.data_ptr(), p.step_ctr.data_ptr(),
+                self._logits.data_ptr(), self._dlogits.data_ptr(), self.gflat.data_ptr(), self._batch)
+
+    def _segments(self, x: torch.Tensor, y: torch.Tensor, auto_step: bool):
+        """The training step as a list of launch segments, cut where a gradient bucket becomes complete:
+        [forward + loss + backward of bucket 0], [backward of bucket 1], ..., [clip + AdamW + shadow refresh].
+        Each segment issues only native kernels on the current stream (capture-safe: no alloc, no sync); the caller
+        starts the bucket's all-reduce between segments."""
+        plan, L = self.plan, self.L
         B = x.shape[0]
         ws = plan.ws
-        plan.generation += 1
         step_arg = 0xFFFFFFFF if auto_step else (self.steps + 1) & 0x7FFFFFFF
-        N.check(L.iq_model_forward(plan.h, x.data_ptr(), B, ws.data_ptr(), ws.numel(), 1, plan.seed, step_arg, None,
-                                   self._logits.data_ptr(), st), "iq_model_forward", plan.h)
-        N.check(L.iq_ce_fwd_bwd(self._logits.data_ptr(), y.data_ptr(), B, plan.cfg.num_classes, self.smoothing,
-                                float(B), self.loss_sum.data_ptr(), self.n_correct.data_ptr(),
-                                self._dlogits.data_ptr(), st), "iq_ce_fwd_bwd")
-        if self.gflat is not plan.gflat:
-            plan._bind_native(self.gflat)
-        for (hi, lo), (off, ln) in zip(self.buckets, self.ranges):
-            N.check(L.iq_model_backward(plan.h, self._dlogits.data_ptr(), None, B, ws.data_ptr(), ws.numel(), 0, hi, lo,
-                                        st), "iq_model_backward", plan.h)
-            self.reducer.launch(self.gflat, off, ln)
-        self.reducer.wait()
-        gscale = 1.0 / self.world
-        N.check(L.iq_gradnorm_sq(self.gflat.data_ptr(), plan.nparam, gscale, self.gn_ws.data_ptr(),
-                                 self.gnorm_sq.data_ptr(), st), "iq_gradnorm_sq")
-        N.check(L.iq_counter_add(None, 0, self.dyn.data_ptr() + 4, 1.0, st), "iq_counter_add")
-        N.check(L.iq_adamw_step(plan.flat.data_ptr(), self.gflat.data_ptr(), self.exp_avg.data_ptr(),
-                                self.exp_avg_sq.data_ptr(), plan.shadow.data_ptr(), plan.nparam, self.lr, self.betas[0],
-                                self.betas[1], self.eps, self.wd, 0, self.gnorm_sq.data_ptr(), self.max_norm, gscale,
-                                self.dyn.data_ptr(), st), "iq_adamw_step")
-        # transposed / padded shadows for the next step's dgrads
-        N.check(L.iq_model_refresh_transposed(plan.h, st), "iq_model_refresh_transposed", plan.h)
+
+        def fwd_and_first_bucket():
+            st = N.stream_handle()
+            N.check(L.iq_model_forward(plan.h, x.data_ptr(), B, ws.data_ptr(), ws.numel(), 1, plan.seed, step_arg, None,
+                                       self._logits.data_ptr(), st), "iq_model_forward", plan.h)
+            N.check(L.iq_ce_fwd_bwd(self._logits.data_ptr(), y.data_ptr(), B, plan.cfg.num_classes, self.smoothing,
+                                    float(B), self.loss_sum.data_ptr(), self.n_correct.data_ptr(),
+                                    self._dlogits.data_ptr(), st), "iq_ce_fwd_bwd")
+            bwd(0)()
+
+        def bwd(i):
+            hi, lo = self.buckets[i]
+
+            def run():
+                N.check(L.iq_model_backward(plan.h, self._dlogits.data_ptr(), None, B, ws.data_ptr(), ws.numel(), 0, hi,
+                                            lo, N.stream_handle()), "iq_model_backward", plan.h)
+            return run
+
+        def optimizer():
+            st = N.stream_handle()
+            gscale = 1.0 / self.world
+            N.check(L.iq_gradnorm_sq(self.gflat.data_ptr(), plan.nparam, gscale, self.gn_ws.data_ptr(),
+                                     self.gnorm_sq.data_ptr(), st), "iq_gradnorm_sq")
+            N.check(L.iq_counter_add(None, 0, self.dyn.data_ptr() + 4, 1.0, st), "iq_counter_add")
+            N.check(L.iq_adamw_step(plan.flat.data_ptr(), self.gflat.data_ptr(), self.exp_avg.data_ptr(),
+                                    self.exp_avg_sq.data_ptr(), plan.shadow.data_ptr(), plan.nparam, self.lr,
+                                    self.betas[0], self.betas[1], self.eps, self.wd, 0, self.gnorm_sq.data_ptr(),
+                                    self.max_norm, gscale, self.dyn.data_ptr(), st), "iq_adamw_step")
+            # transposed / padded shadows for the next step's dgrads
+            N.check(L.iq_model_refresh_transposed(plan.h, st), "iq_model_refresh_transposed", plan.h)
+
+        return [fwd_and_first_bucket] + [bwd(i) for i in range(1, len(self.buckets))] + [optimizer]
+
+    def _run_segments(self, runners):
+        """runners[i]() issues segment i; bucket i's all-reduce starts as soon as segment i is on the stream and
+        overlaps the following segments; the optimizer segment waits for all of them."""
+        nb = len(self.buckets)
+        for i, run in enumerate(runners):
+            if i == nb:
+                self.reducer.wait()
+            run()
+            if i < nb:
+                off, ln = self.ranges[i]
+                self.reducer.launch(self.gflat, off, ln)
 
     def step(self, x: torch.Tensor, y: torch.Tensor):
         """One optimizer step on a batch already resident in HBM.  Asynchronous."""
@@ -170,29 +222,48 @@ class FusedTrainer:
         x = x.contiguous().float()
         y = y.contiguous().long()
         B = x.shape[0]
+        plan = self.plan
+        if not plan.is_bound(self.device):
+            # the parameters were re-homed behind the trainer's back (model.to(), a second plan, p.data = ...): adopt
+            # their CURRENT values instead of updating a buffer nobody reads any more
+            plan.ensure(self.device)
         self._buffers(B)
+        if self.gflat is not plan.gflat:
+            plan._bind_native(self.gflat)
+        plan.generation += 1
         if self.use_graph:
-            if self._graph is None:
+            if self._graphs is not None and self._captured != self._pointers():
+                self._graphs = None          # a captured buffer moved (workspace regrown by an eval forward, rebinding)
+            if plan.ctr_value != self.steps:
+                plan.step_ctr.fill_(self.steps)      # something else ran a training forward: re-sync the device step
+                plan.ctr_value = self.steps
+            if self._graphs is None:
                 # first call: one eager step on static buffers (this call's step; also warms lazy kernel
                 # attributes and the allocator), then capture the identical launch sequence for later replays
-                self._static = (torch.empty_like(x), torch.empty_like(y))
+                if self._static is None or self._static[0].shape != x.shape:
+                    self._static = (torch.empty_like(x), torch.empty_like(y))
                 self._static[0].copy_(x)
                 self._static[1].copy_(y)
-                self._launch(self._static[0], self._static[1], auto_step=True)
+                self._run_segments(self._segments(self._static[0], self._static[1], auto_step=True))
                 torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._launch(self._static[0], self._static[1], auto_step=True)
-                self._graph = g
+                graphs = []
+                for seg in self._segments(self._static[0], self._static[1], auto_step=True):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        seg()
+                    graphs.append(g)
+                self._graphs = graphs
+                self._captured = self._pointers()
             else:
                 self._static[0].copy_(x, non_blocking=True)
                 self._static[1].copy_(y, non_blocking=True)
-                self._graph.replay()
+                self._run_segments([g.replay for g in self._graphs])
         else:
-            self._launch(x, y, auto_step=False)
+            self._run_segments(self._segments(x, y, auto_step=False))
         self.steps += 1
         self.frames_seen += B
-        self.plan.step = self.steps
+        plan.step = self.steps
+        plan.ctr_value = self.steps
 
     # ------------------------------------------------------------------------------------------
     def read_stats(self, reset=True):
