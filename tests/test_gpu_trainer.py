@@ -63,8 +63,11 @@ def test_fused_step_matches_oracle_step(name):
         total += int(big.sum())
         assert (d_got - d_ref).abs().max().item() <= 6.5 * lr, k      # nobody moves further than 3 full steps apart
         # trajectory as a whole: the update of every parameter tensor points where the oracle's does
-        if d_ref.numel() >= 64 and d_ref.norm() > 0:
-            cos = float((d_ref * d_got).sum() / (d_ref.norm() * d_got.norm() + 1e-30))
+        # (over the elements whose gradient dominated eps: the K bias has a true gradient of 0 -- softmax is shift
+        #  invariant -- and AdamW turns its 1e-9 rounding noise into +-lr steps of random sign)
+        if int(big.sum()) >= 64:
+            a_, b_ = d_ref[big], d_got[big]
+            cos = float((a_ * b_).sum() / (a_.norm() * b_.norm() + 1e-30))
             assert cos > 0.9, (k, cos)
     assert total > 1000 and agree / total > 0.985, (agree, total)
     # the step left the bf16 shadows consistent: an eval forward through the module path matches the oracle
