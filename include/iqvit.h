@@ -80,6 +80,18 @@ typedef struct iq_epilogue {
 int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                     const iq_epilogue_t* epi, iq_stream_t stream);
 
+/* GEMM + the post-norm tail of an encoder sub-layer in ONE launch (whole-row tiles, D in {128,192,256}, K % 32 == 0, K >= 64):
+ *   Z = dropout(A[M,K] * W[D,K]^T + bias) + residual        bf16 [M,D]   (kept for backward)
+ *   X = gamma * (Z - mean) * rstd + beta                     bf16 [M,D];  mean, rstd fp32 [M] (kept for backward)
+ * Replaces `x = norm1(dropout1(attention(x)) + x)` / `x = norm2(dropout2(ffn(x)) + x)`,
+ * V/models/blocks/encoder_layer.py:24-25,32-33 with LayerNorm.forward (V/models/layers/layers_norm.py:11-19), i.e. an
+ * iq_gemm_bf16_nt (bias, dropout, residual) followed by iq_ln_fwd: same Z bit for bit, same statistics to fp32
+ * summation order (taken from the bf16-rounded Z, two-pass).  All pointers 16-byte aligned. */
+int iq_gemm_ln_supported(int D, int K);
+int iq_gemm_bf16_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr,
+                    const iq_dropout_t* drop, const float* gamma, const float* beta, float eps, void* Z, void* X,
+                    float* mean, float* rstd, int M, int D, int K, iq_stream_t stream);
+
 /* Two chained NT GEMMs in one launch: H[M,F] = epi1(X[M,D] * Wa[F,D]^T); Y[M,D] = epi2(H * Wb[D,F]^T).
  * Replaces PositionwiseFeedForward.forward (V/models/layers/position_wise_feed_forward.py:12-17) + dropout2 + residual
  * (V/models/blocks/encoder_layer.py:30-33), and -- with the transposed weight shadows and epi1 = gate -- its data-gradient

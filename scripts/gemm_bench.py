@@ -37,6 +37,8 @@ def wg(N_, K):
     byt = 2 * (M * N_ + M * K) + 4 * N_ * K
     print(f"wgrad N={N_:5d} K={K:5d}: {us:8.1f} us  {byt/us/1e3:7.1f} GB/s  {2*M*N_*K/us/1e6:7.1f} TFLOP/s  (slab ws {nb/1e6:.1f} MB)")
 print(f"M = {M}")
+if len(sys.argv) > 2:
+    nt = wg = lambda *a, **k: None
 nt(576, 192, bias=True)
 nt(192, 192)
 nt(192, 192, bias=True, res=True)
@@ -49,3 +51,22 @@ nt(192, 768, bias=True, drop=0.1, res=True)
 nt(768, 192, gate=True)
 nt(192, 576, res=True)
 wg(192, 768); wg(768, 192); wg(192, 192); wg(576, 192)
+def gemm_ln(D, K, drop=0.1):
+    """fused GEMM + dropout + residual + LayerNorm vs the two launches it replaces"""
+    A = torch.randn(M, K, device=d).bfloat16(); W = (torch.randn(D, K, device=d) / math.sqrt(K)).bfloat16()
+    R = torch.randn(M, D, device=d).bfloat16(); bias = torch.randn(D, device=d); gm = torch.rand(D, device=d) + 0.5; bt = torch.randn(D, device=d)
+    Z = torch.empty(M, D, device=d, dtype=torch.bfloat16); X = torch.empty_like(Z); mean = torch.empty(M, device=d); rstd = torch.empty(M, device=d)
+    dr = N.Dropout(); dr.p = drop; dr.seed = 1; dr.site = 2; dr.step = 3
+    e = N.Epilogue(); e.bias = bias.data_ptr(); e.drop = dr; e.residual = R.data_ptr(); e.ldr = D
+    def two():
+        L.iq_gemm_bf16_nt(A.data_ptr(), K, W.data_ptr(), K, Z.data_ptr(), D, M, D, K, C.byref(e), st())
+        L.iq_ln_fwd(Z.data_ptr(), gm.data_ptr(), bt.data_ptr(), X.data_ptr(), mean.data_ptr(), rstd.data_ptr(), M, D, 1e-12, st())
+    def one():
+        L.iq_gemm_bf16_ln(A.data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), R.data_ptr(), D, C.byref(dr), gm.data_ptr(), bt.data_ptr(), 1e-12,
+                          Z.data_ptr(), X.data_ptr(), mean.data_ptr(), rstd.data_ptr(), M, D, K, st())
+    t2, t1 = timeit(two), timeit(one)
+    byt = 2 * (M * K + D * K + 3 * M * D) + 8 * M
+    print(f"gemm+ln D={D:4d} K={K:5d} drop={drop}: two launches {t2:7.1f} us, fused {t1:7.1f} us  ({byt/t1/1e3:7.1f} GB/s algorithmic)")
+if len(sys.argv) > 2 and sys.argv[2] == "ln":
+    for D_, K_ in ((192, 192), (192, 768), (128, 128), (128, 1024), (256, 256), (256, 1024)):
+        gemm_ln(D_, K_, 0.1); gemm_ln(D_, K_, 0.0)

@@ -177,6 +177,51 @@ def test_gemm_wide_n_many_rows(L, M, N_, K):
     assert torch.equal((out_s.float() != 0)[sel], keep[:Ms][sel])
 
 
+@pytest.mark.parametrize("D,K", [(192, 192), (192, 768), (128, 128), (128, 1024), (256, 256), (256, 1024), (128, 64)])
+@pytest.mark.parametrize("M,pdrop", [(1000, 0.0), (50432, 0.1), (130, 0.25), (77, 0.0)])
+def test_gemm_with_fused_layernorm_tail_equals_gemm_then_layernorm(L, D, K, M, pdrop):
+    """iq_gemm_bf16_ln (out-projection / FFN2 + dropout + residual + LayerNorm in one launch, encoder_layer.py:24-25,32-33)
+    against the two-kernel path it replaces (iq_gemm_bf16_nt with the same epilogue, then iq_ln_fwd): Z bit for bit
+    (same MFMA order, same Philox mask), statistics to fp32 summation order, X within one bf16 ulp; and both against fp64."""
+    N = _N()
+    assert L.iq_gemm_ln_supported(D, K) == 1 and L.iq_gemm_ln_supported(768, 768) == 0 and L.iq_gemm_ln_supported(192, 40) == 0
+    g = torch.Generator(device="cuda").manual_seed(M + D + K)
+    A = bf(torch.randn(M, K, device=dev(), generator=g))
+    W = bf(torch.randn(D, K, device=dev(), generator=g) / math.sqrt(K))
+    R = bf(torch.randn(M, D, device=dev(), generator=g) + 0.2)
+    bias = torch.randn(D, device=dev(), generator=g)
+    gamma = torch.rand(D, device=dev(), generator=g) + 0.5
+    beta = torch.randn(D, device=dev(), generator=g)
+    dr = _drop(1234, 7, 4, pdrop)
+    # two-kernel path
+    Z0 = run_gemm(L, A, W, M, D, K, bias=bias, drop=dr, residual=R, ldr=D) if pdrop > 0 else run_gemm(L, A, W, M, D, K, bias=bias, residual=R, ldr=D)
+    X0 = torch.empty_like(Z0)
+    mean0 = torch.empty(M, device=dev()); rstd0 = torch.empty(M, device=dev())
+    N.check(L.iq_ln_fwd(Z0.data_ptr(), gamma.data_ptr(), beta.data_ptr(), X0.data_ptr(), mean0.data_ptr(), rstd0.data_ptr(),
+                        M, D, 1e-12, stream()), "ln_fwd")
+    # fused
+    Z1 = torch.full((M, D), float("nan"), dtype=torch.bfloat16, device=dev())
+    X1 = torch.full((M, D), float("nan"), dtype=torch.bfloat16, device=dev())
+    mean1 = torch.full((M,), float("nan"), device=dev()); rstd1 = torch.full((M,), float("nan"), device=dev())
+    N.check(L.iq_gemm_bf16_ln(A.data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), R.data_ptr(), D, C.byref(dr) if pdrop > 0 else None,
+                              gamma.data_ptr(), beta.data_ptr(), 1e-12, Z1.data_ptr(), X1.data_ptr(), mean1.data_ptr(),
+                              rstd1.data_ptr(), M, D, K, stream()), "gemm_ln")
+    assert torch.equal(Z0.view(torch.int16), Z1.view(torch.int16)), "Z differs from the two-kernel path"
+    assert torch.allclose(mean0, mean1, rtol=0, atol=2e-6 * (mean0.abs().max().item() + 1))
+    assert torch.allclose(rstd0, rstd1, rtol=2e-6, atol=0)
+    ulp = (X0.float() - X1.float()).abs() / (X0.float().abs() * 2 ** -7 + 1e-6)
+    assert ulp.max().item() <= 1.0 + 1e-3, ulp.max().item()
+    assert (X0.view(torch.int16) != X1.view(torch.int16)).float().mean().item() < 1e-3      # and almost always identical
+    if pdrop == 0.0:
+        zf = (A.double() @ W.double().t() + bias.double()) + R.double()
+        close_bf16(Z1, zf, "Z vs fp64")
+        zb = Z1.double()
+        mu = zb.mean(-1, keepdim=True); var = zb.var(-1, unbiased=False, keepdim=True)
+        close_bf16(X1, gamma.double() * ((zb - mu) / torch.sqrt(var + 1e-12)) + beta.double(), "X vs fp64")
+        close_f32(mean1, mu.squeeze(-1), "mean", 1e-5)
+        close_f32(rstd1, (1 / torch.sqrt(var + 1e-12)).squeeze(-1), "rstd", 1e-5)
+
+
 def _epi(N, **kw):
     e = N.Epilogue()
     for k, v in kw.items():

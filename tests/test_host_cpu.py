@@ -167,3 +167,12 @@ def test_bucket_plan_covers_every_stage_once():
                 assert hi >= lo
                 stages += list(range(hi, lo - 1, -1))
             assert stages == list(range(L_ + 1, -1, -1))
+
+
+def test_counted_tail_waits_match_the_isa():
+    """The GEMM kernels wait for their last operand stage with `s_waitcnt vmcnt(N)`, N = the tail loads issued behind it.
+    That is only correct if the compiler emitted at least N loads there: checked in the gfx950 ISA (hipcc cross-compiles)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dbg", "check_epi_counts.py")], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "ok:" in r.stdout

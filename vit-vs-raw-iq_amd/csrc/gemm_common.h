@@ -81,6 +81,36 @@ __device__ __forceinline__ void epi_load(const GemmParams& p, EpiRegs<MT, NT, EP
   }
 }
 
+// The tail's loads with NO predicate: rows / columns outside the problem are clamped to valid addresses (their values are
+// never stored) and `p.bias` must be non-null (the host passes a zero vector when the caller gave none), so the number
+// of vector-memory instructions is the compile-time constant EPI_EARLY_LOADS.  A kernel can then issue them behind its
+// last operand stage and keep waiting for that stage with a COUNTED vmcnt: they fly under the last MFMAs instead of
+// after them (tools/check at build time: scripts/dbg/check_epi_counts.py counts them in the ISA).  R.rng is not touched.
+template <int MT, int NT, int EPI>
+constexpr int epi_early_loads() {
+  return 2 * (NT / 2) + MT * (NT / 2) * (((EPI & EPI_RES) ? 1 : 0) + ((EPI & EPI_GATE) ? 1 : 0));
+}
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void epi_load_early(const GemmParams& p, EpiRegs<MT, NT, EPI>& R, int row0, int col0, int lane) {
+  static_assert(!((EPI & EPI_RES) && (EPI & EPI_PE)), "the row-remapped residual is not used by any caller");
+  constexpr int NP = NT / 2;
+  const int g = lane >> 4, c16 = lane & 15;
+  const bool odd = (g & 1) != 0;
+#pragma unroll
+  for (int jp = 0; jp < NP; ++jp) {
+    int col = col0 + (odd ? (2 * jp + 1) * 16 + 4 * (g - 1) : (2 * jp) * 16 + 4 * g);
+    col = col < p.N ? col : 0;
+    R.bias_lo[jp] = *reinterpret_cast<const f32x4*>(p.bias + col);
+    R.bias_hi[jp] = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const long gm = min(row0 + i * 16 + c16, p.M - 1);
+      if (EPI & EPI_RES) R.res[i][jp] = *reinterpret_cast<const bf16x8*>(p.residual + gm * p.ldr + col);
+      if (EPI & EPI_GATE) R.gt[i][jp] = *reinterpret_cast<const bf16x8*>(p.gate + gm * p.ldg + col);
+    }
+  }
+}
+
 // LDSOUT (chained GEMMs, gemm_chain.hip): the rounded bf16 tile is ALSO left in LDS as the A operand of the next
 // product: [rows][256 B] image at `hs`, 16 B chunk c of row r at chunk c ^ (r & 15); (lrow0, lcol0) = the wave tile's
 // origin inside that image.

@@ -141,7 +141,12 @@ typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 // epilogue's `+ residual`), and the epilogue has no loads left -- what made the 192-column tile lose 9-12 us per launch
 // to an exposed residual fetch (2 workgroups per CU) now arrives prefetched like any operand stage.
 template <int BMT, int BN, int EPI, bool RESK = false>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmParams p) {
+// Variants whose tail loads a residual / gate tile issue those loads EARLY (below) and state 2 waves per SIMD to the
+// register allocator, which keeps the accumulators in VGPRs: with the default bound the compiler split them over VGPRs
+// and AGPRs and, once the last two stages were peeled, shuttled them through v_accvgpr moves inside the K loop.
+// Bias-only variants keep the plain loop and the default allocation (99 VGPR + 64 AGPR, three workgroups per CU): for
+// them the early form measured SLOWER (FFN1 shape 33.2 -> 38.5 us, QKV 27.7 -> 31.5), with nothing worth prefetching.
+__global__ __launch_bounds__(GEMM_THREADS, RESK ? 3 : ((EPI & ~EPI_PE) == 0 ? 1 : 2)) void gemm_nt_async_kernel(const GemmParams p) {
   constexpr int BK2 = 32;
   constexpr int WN = BN / 2, NT = WN / 16, MT = BMT / 32;   // wave tile = BMT/2 rows x BN/2 cols
   constexpr int STAGE_BYTES = (BMT + BN) * BK2 * 2;
@@ -227,6 +232,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
     const int d = (int)(((unsigned)blockIdx.x * 2654435761u) >> 30) * p.stagger;   // 0..3 x stagger
     for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(8);
   }
+  // the tail's registers; the device-resident dropout step is loaded FIRST (oldest entry of the in-order vmcnt queue)
+  constexpr int EPIX = RESK ? (EPI & ~EPI_RES) : EPI;
+  EpiRegs<MT, NT, EPIX> R;
+  R.rng = p.drop_on ? rng_resolve(p.rng) : p.rng;
   IQ_STAMP(0);
   issue(0);
   if (ntot > 1) issue(1);
@@ -244,9 +253,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
     if (ks + 2 < ntot) issue(ks + 2);
   };
   const int ch = lane >> 4;
-  for (int ks = 0; ks < nk; ++ks) {
-    stage_begin(ks);
-    if (ks == 0) IQ_STAMP(1);
+  auto compute = [&](int ks) {
     const bf16* As = reinterpret_cast<const bf16*>(smem + (ks % NS) * STAGE_BYTES);
     const bf16* Bs = As + BMT * BK2;
     bf16x8 af[MT], bfr[NT];
@@ -272,6 +279,47 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
       for (int j = 0; j < NT; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile: see gemm_epilogue
 #endif
+  };
+  const int row0 = m0 + (wave >> 1) * (BMT / 2), col0 = n0 + (wave & 1) * (BN / 2);
+  constexpr bool EARLY_TAIL = !RESK && (EPIX & (EPI_RES | EPI_GATE)) != 0;
+  if constexpr (EARLY_TAIL) {
+    // The tail's global loads (bias, residual, gate) go out as soon as the LAST operand stage has been issued and
+    // travel under the last two stages' MFMAs: they are the youngest entries of the in-order vmcnt queue, so the
+    // remaining stage waits leave exactly EARLY of them outstanding.  (Issued BEFORE the K loop they made every stage
+    // wait behind them -- measured slower, profiles/r01_probes.txt; after the loop their latency was exposed.)
+    // The two last stages are peeled: with the register loads inside the loop body the compiler drains the whole
+    // queue (vmcnt(0)) on every iteration.
+    constexpr int EARLY = epi_early_loads<MT, NT, EPIX>();
+    for (int ks = 0; ks + 2 < nk; ++ks) {
+      stage_begin(ks);
+      if (ks == 0) IQ_STAMP(1);
+      compute(ks);
+    }
+    if (nk >= 2) {
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER_STAGE) : "memory");      // stage nk-2 landed, nk-1 in flight
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      epi_load_early<MT, NT, EPIX>(p, R, row0, col0, lane);
+      asm volatile("" ::: "memory");                                          // ... issued now, not after this stage's MFMAs
+      compute(nk - 2);
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(EARLY) : "memory");          // stage nk-1 landed; only the tail's loads fly
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      compute(nk - 1);
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      epi_load_early<MT, NT, EPIX>(p, R, row0, col0, lane);
+      asm volatile("" ::: "memory");
+      compute(0);
+    }
+  } else {
+    for (int ks = 0; ks < nk; ++ks) {
+      stage_begin(ks);
+      if (ks == 0) IQ_STAMP(1);
+      compute(ks);
+    }
   }
   if (RESK) {
     // residual stage t covers columns [32 t, 32 t + 32) = column tiles 2t and 2t+1 of the row: the wave that owns them
@@ -300,8 +348,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
     }
   }
   IQ_STAMP(2);
+  if constexpr (!EARLY_TAIL) {    // bias-only tails (and RESK, whose residual came through the ring): load after the loop
+    const IqRng keep = R.rng;
+    epi_load<MT, NT, EPIX>(p, R, row0, col0, lane);
+    R.rng = keep;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): the tail's loads have landed
   IQ_STAMP(3);
-  gemm_epilogue<MT, NT, RESK ? (EPI & ~EPI_RES) : EPI>(p, acc, m0 + (wave >> 1) * (BMT / 2), n0 + (wave & 1) * (BN / 2), lane);
+  epi_finish<MT, NT, EPIX>(p, acc, R, row0, col0, lane);
   IQ_STAMP(4);
 #ifdef IQ_GEMM_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // only to time the store drain: a wave may retire with stores in flight
@@ -310,6 +364,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_async_kernel(const GemmP
 }
 
 }  // namespace
+
+// all-zero bias for calls without one: the early tail loads are unconditional (gemm_common.h, epi_load_early)
+constexpr int ZERO_BIAS_FLOATS = 16384;
+__device__ float g_zero_bias[ZERO_BIAS_FLOATS];
+static const float* zero_bias() {
+  static const float* ptr = [] {
+    void* q = nullptr;
+    return hipGetSymbolAddress(&q, HIP_SYMBOL(g_zero_bias)) == hipSuccess ? (const float*)q : (const float*)nullptr;
+  }();
+  return ptr;
+}
 
 #ifdef IQ_GEMM_STAMPS
 static unsigned long long* g_stamps = nullptr;
@@ -355,10 +420,15 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   int epi_mode = (p.residual ? EPI_RES : 0) | (p.gate ? EPI_GATE : 0) | ((p.pe || p.tok > 0) ? EPI_PE : 0);
   if ((epi_mode & EPI_PE) && (!p.pe || p.tok <= 0 || (epi_mode & (EPI_RES | EPI_GATE)))) return IQ_ERR_UNSUPPORTED;
   if (p.bias && ((uintptr_t)p.bias % 16)) return IQ_ERR_ARG;
+  const bool has_bias = p.bias != nullptr;
+  if (!has_bias) {
+    if (N > ZERO_BIAS_FLOATS || !zero_bias()) return IQ_ERR_UNSUPPORTED;
+    p.bias = zero_bias();
+  }
   p.stagger = 2;      // measured best of {0, 2, 6} (profiles/r01_probes.txt)
   // C = A W^T + R, nothing else in the tail, whole rows in one 192- / 128-column tile: residual streamed as extra K stages.
   // (the plain 192-column tile reads A once -- N=192 K=768: 27.6 vs 37.3 us -- but lost it all to an exposed residual fetch)
-  if (async_ok && epi_mode == EPI_RES && (N == 192 || N == 128) && K >= 384 && !p.bias && !p.relu && !p.drop_on &&
+  if (async_ok && epi_mode == EPI_RES && (N == 192 || N == 128) && K >= 384 && !has_bias && !p.relu && !p.drop_on &&
       ((uintptr_t)p.residual % 16) == 0) {
     p.tiles_m = (M + BM - 1) / BM;
     p.tiles_n = 1;

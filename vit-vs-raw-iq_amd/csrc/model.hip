@@ -231,6 +231,11 @@ WsPlan plan_ws(const iq_model* m, int B) {
   return w;
 }
 
+// The fused GEMM + LayerNorm launch where it was measured faster than GEMM then LayerNorm (scripts/gemm_bench.py ... ln,
+// M = 50432: D 192 K 192 22.4 vs 25.9 us, K 768 38.9 vs 46.0; D 128 K 128 16.3 vs 20.6, K 1024 31.4 vs 34.4; D 256 K 256 31.6 vs
+// 33.1 but K 1024 62.3 vs 55.7: its 64-row blocks re-stream the 512 KB weight twice as often).
+inline bool use_fused_ln(int D, int K) { return iq_gemm_ln_supported(D, K) && (D <= 192 || K <= 256); }
+
 #define IQ_TRY(expr, what)                                                              \
   do {                                                                                  \
     int rc_ = (expr);                                                                   \
@@ -467,19 +472,31 @@ extern "C" int iq_model_forward(iq_model_t* m, const float* src, int batch, void
     e.bias = P + o.bqkv;
     IQ_TRY(iq_gemm_bf16_nt(x, D, m->sh(o.wqkv), D, ws + a.qkv, 3 * D, M, 3 * D, D, &e, stream), "qkv GEMM");
     IQ_TRY(iq_attn_fwd(ws + a.qkv, ws + a.att, (float*)(ws + a.lse), B, S, H, m->dh, stream), "attention fwd");
-    // out-proj + dropout1 + residual, then norm1
-    memset(&e, 0, sizeof(e));
-    e.bias = P + o.bo; e.drop = site(m, seed, step_dev, 1 + 3 * l, tr); e.residual = x; e.ldr = D;
-    IQ_TRY(iq_gemm_bf16_nt(ws + a.att, D, m->sh(o.wo), D, ws + a.z1, D, M, D, D, &e, stream), "out-proj GEMM");
-    IQ_TRY(iq_ln_fwd(ws + a.z1, P + o.g1, P + o.be1, ws + a.x1, (float*)(ws + a.mean1), (float*)(ws + a.rstd1), M, D, 1e-12f, stream), "norm1");
+    // out-proj + dropout1 + residual + norm1: one launch when a workgroup can own whole rows (D <= 256), else two
+    const iq_dropout_t dr1 = site(m, seed, step_dev, 1 + 3 * l, tr);
+    if (use_fused_ln(D, D)) {
+      IQ_TRY(iq_gemm_bf16_ln(ws + a.att, D, m->sh(o.wo), D, P + o.bo, x, D, &dr1, P + o.g1, P + o.be1, 1e-12f, ws + a.z1,
+                             ws + a.x1, (float*)(ws + a.mean1), (float*)(ws + a.rstd1), M, D, D, stream), "out-proj GEMM + norm1");
+    } else {
+      memset(&e, 0, sizeof(e));
+      e.bias = P + o.bo; e.drop = dr1; e.residual = x; e.ldr = D;
+      IQ_TRY(iq_gemm_bf16_nt(ws + a.att, D, m->sh(o.wo), D, ws + a.z1, D, M, D, D, &e, stream), "out-proj GEMM");
+      IQ_TRY(iq_ln_fwd(ws + a.z1, P + o.g1, P + o.be1, ws + a.x1, (float*)(ws + a.mean1), (float*)(ws + a.rstd1), M, D, 1e-12f, stream), "norm1");
+    }
     // ffn
     memset(&e, 0, sizeof(e));
     e.bias = P + o.b1; e.relu = 1; e.drop = site(m, seed, step_dev, 2 + 3 * l, tr);
     IQ_TRY(iq_gemm_bf16_nt(ws + a.x1, D, m->sh(o.w1), D, ws + a.hid, F, M, F, D, &e, stream), "ffn1 GEMM");
-    memset(&e, 0, sizeof(e));
-    e.bias = P + o.b2; e.drop = site(m, seed, step_dev, 3 + 3 * l, tr); e.residual = ws + a.x1; e.ldr = D;
-    IQ_TRY(iq_gemm_bf16_nt(ws + a.hid, F, m->sh(o.w2), F, ws + a.z2, D, M, D, F, &e, stream), "ffn2 GEMM");
-    IQ_TRY(iq_ln_fwd(ws + a.z2, P + o.g2, P + o.be2, ws + a.x2, (float*)(ws + a.mean2), (float*)(ws + a.rstd2), M, D, 1e-12f, stream), "norm2");
+    const iq_dropout_t dr2 = site(m, seed, step_dev, 3 + 3 * l, tr);
+    if (use_fused_ln(D, F)) {
+      IQ_TRY(iq_gemm_bf16_ln(ws + a.hid, F, m->sh(o.w2), F, P + o.b2, ws + a.x1, D, &dr2, P + o.g2, P + o.be2, 1e-12f,
+                             ws + a.z2, ws + a.x2, (float*)(ws + a.mean2), (float*)(ws + a.rstd2), M, D, F, stream), "ffn2 GEMM + norm2");
+    } else {
+      memset(&e, 0, sizeof(e));
+      e.bias = P + o.b2; e.drop = dr2; e.residual = ws + a.x1; e.ldr = D;
+      IQ_TRY(iq_gemm_bf16_nt(ws + a.hid, F, m->sh(o.w2), F, ws + a.z2, D, M, D, F, &e, stream), "ffn2 GEMM");
+      IQ_TRY(iq_ln_fwd(ws + a.z2, P + o.g2, P + o.be2, ws + a.x2, (float*)(ws + a.mean2), (float*)(ws + a.rstd2), M, D, 1e-12f, stream), "norm2");
+    }
     x = ws + a.x2;
   }
   if (logits) {
