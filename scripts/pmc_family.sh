@@ -1,27 +1,52 @@
 #!/bin/bash
-# HBM traffic of the gemm_nt kernel family over whole training steps (cfg B, eager launches): two separate --pmc passes
-# (FETCH_SIZE, WRITE_SIZE; guide: no trace domains combined with --pmc), summed per dispatch and averaged.
+# PMC passes over whole training steps (eager launches), one rocprofv3 run per counter set (guide: FETCH_SIZE and WRITE_SIZE
+# do not fit one pass; no trace domain other than --kernel-trace next to --pmc).
+#   scripts/pmc_family.sh <config B|C|...> <out.json>
+# Per kernel family: HBM-side bytes per launch (FETCH_SIZE x2: gfx950 counts 64 B per 128 B request, MI355X_MICROARCH.md
+# "HBM"; WRITE_SIZE as is).  Whole step: MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8).
+cfg=${1:-B}; out=${2:-gpurun_out/pmc_family_cfg$cfg.json}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc_family/$ctr -- python3 bench.py --graph 0 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pmc_family_$ctr.log 2>&1 || echo "pass $ctr failed"
+i=0
+for ctr in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc_family_$cfg/p$i -- python3 bench.py --config $cfg --graph 0 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary > gpurun_out/pmc_family_${cfg}_p$i.log 2>&1 || echo "pass $i failed"
 done
-python3 - <<'PY'
-import csv, glob, json, collections
+python3 - "$cfg" "$out" <<'PY'
+import csv, glob, json, collections, sys
+cfg, out_path = sys.argv[1], sys.argv[2]
+def fam_of(k):
+    if "gemm_nt" in k or "gemm_ln" in k or "gemm_chain" in k: return "gemm_nt"
+    if "wgrad" in k: return "wgrad"
+    if "attn_bwd" in k: return "attn_bwd"
+    if "attn_fwd" in k: return "attn_fwd"
+    if "ln_bwd" in k: return "ln_bwd"
+    if "ln_fwd" in k: return "ln_fwd"
+    return "misc"
 tot = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(lambda: collections.defaultdict(int))
-for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-    for f in glob.glob(f"gpurun_out/pmc_family/{ctr}/*/*counter_collection.csv"):
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != ctr: continue
-            k = r["Kernel_Name"]
-            fam = "gemm_nt" if "gemm_nt" in k else "wgrad" if "wgrad_pw" in k or "wgrad_kernel" in k else "attn_bwd" if "attn_bwd" in k else "attn_fwd" if "attn_fwd" in k else "ln_bwd" if "ln_bwd_kernel" in k else "ln_fwd" if "ln_fwd" in k else None
-            if fam: tot[fam][ctr] += float(r["Counter_Value"]); cnt[fam][ctr] += 1
+for f in glob.glob(f"gpurun_out/pmc_family_{cfg}/p*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "at::native" in k or "rocclr" in k: continue
+        fam = fam_of(k); c = r["Counter_Name"]
+        tot[fam][c] += float(r["Counter_Value"])
+        if "wgrad_reduce" not in k: cnt[fam][c] += 1     # a weight-gradient call = its GEMM launch + its slab reduce
 out = {}
+allc = collections.defaultdict(float)
 for fam in tot:
-    n = cnt[fam]["FETCH_SIZE"]
-    fetch_kb = tot[fam]["FETCH_SIZE"] / max(n, 1) * 2.0      # gfx950: FETCH_SIZE under-counts by 2 (MI355X_MICROARCH guide)
+    for c, v in tot[fam].items(): allc[c] += v
+    if fam == "misc": continue
+    n = max(cnt[fam]["FETCH_SIZE"], 1)
+    fetch_kb = tot[fam]["FETCH_SIZE"] / n * 2.0      # gfx950: FETCH_SIZE under-counts wide streaming reads by 2
     write_kb = tot[fam]["WRITE_SIZE"] / max(cnt[fam]["WRITE_SIZE"], 1)
-    out[fam] = {"dispatches": n, "fetch_bytes_per_launch": fetch_kb * 1024, "write_bytes_per_launch": write_kb * 1024,
-                "hbm_bytes_per_launch": (fetch_kb + write_kb) * 1024}
+    e = {"dispatches": cnt[fam]["FETCH_SIZE"], "fetch_bytes_per_launch": fetch_kb * 1024, "write_bytes_per_launch": write_kb * 1024,
+         "hbm_bytes_per_launch": (fetch_kb + write_kb) * 1024}
+    if tot[fam].get("GRBM_GUI_ACTIVE"):
+        e["mfma_util"] = round(tot[fam]["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * tot[fam]["GRBM_GUI_ACTIVE"] / 8.0), 4)
+    out[fam] = e
+if allc.get("GRBM_GUI_ACTIVE"):
+    out["mfma_util"] = round(allc["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * allc["GRBM_GUI_ACTIVE"] / 8.0), 4)
+    out["mfma_util_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), all native kernels of 4 training steps"
+    out["sq_insts_mfma_per_step"] = allc["SQ_INSTS_MFMA"] / 4.0
 print(json.dumps(out, indent=1))
-json.dump(out, open("gpurun_out/pmc_family.json", "w"), indent=1)
+json.dump(out, open(out_path, "w"), indent=1)
 PY
