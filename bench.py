@@ -79,17 +79,24 @@ def param_count(g):
     return D * P + D + D + L * per_layer + D * K + K
 
 
-def family_work(g, B, training_dropout, fused_ln):
+def family_work(g, B, training_dropout, fused_ln, ln_bwd_launches):
     """Algorithmic bytes / flops per training step and launches per step for each kernel family
-    (DESIGN.md section 'Kernels and rooflines' derives the same numbers)."""
+    (DESIGN.md section 'Kernels and rooflines' derives the same numbers).  fused_ln: the LayerNorm forward rides in the
+    out-projection / FFN2 GEMM (it also writes the normalised rows); ln_bwd_launches: stand-alone LayerNorm backward
+    launches left per step -- the others ride in the FFN1 / QKV data-gradient GEMM, which then reads Z and writes dZ (+ dY
+    under dropout) instead of writing dX."""
     D, F, L, H, dh, S, tok, Ppad = g["D"], g["F"], g["L"], g["H"], g["dh"], g["S"], g["tok"], g["Ppad"]
     M, MT = B * S, B * tok
     nt = []   # (M, N, K, extra_MN_reads, extra_MN_writes)
     nt.append((MT, D, Ppad, 0, 0))                 # embedding
     ln_out = 1 if fused_ln else 0                  # out-proj / ffn2 also write the LayerNorm output when fused
-    for _ in range(L):
+    fused_bwd = 2 * L - ln_bwd_launches            # LayerNorm backwards inside a data-gradient GEMM
+    dy = 1 if training_dropout else 0
+    for l in range(L):
+        f1 = 1 if fused_bwd >= 2 * L - 1 or (fused_bwd > 0 and False) else 0     # norm1 backward in the FFN1 data gradient
+        f2 = 1 if fused_bwd >= 2 * L - 1 and l > 0 else 0                        # norm2 backward of layer l-1 in layer l's QKV data gradient
         nt += [(M, 3 * D, D, 0, 0), (M, D, D, 1, ln_out), (M, F, D, 0, 0), (M, D, F, 1, ln_out)]   # fwd: qkv, out(+res), ffn1, ffn2(+res)
-        nt += [(M, F, D, 1, 0), (M, D, F, 1, 0), (M, D, D, 0, 0), (M, D, 3 * D, 1, 0)]             # dgrad: ffn2(+gate), ffn1(+res), out, qkv(+res)
+        nt += [(M, F, D, 1, 0), (M, D, F, 1 + f1, f1 * dy), (M, D, D, 0, 0), (M, D, 3 * D, 1 + f2, f2 * dy)]   # dgrad: ffn2(+gate), ffn1(+res), out, qkv(+res)
     b_nt = sum(2 * (m * k + n * k + m * n) + 2 * m * n * (ex + wx) for m, n, k, ex, wx in nt)
     f_nt = sum(2 * m * n * k for m, n, k, ex, wx in nt)
     wg = [(MT, D, Ppad)]
@@ -102,14 +109,14 @@ def family_work(g, B, training_dropout, fused_ln):
     b_ab = L * (2 * M * 3 * D * 2 + 2 * M * D * 2 + 4 * B * H * S)
     f_ab = L * 14 * B * H * S * S * dh          # 7 MFMA products (S and dP are computed in both phases)
     b_lf = 0 if fused_ln else 2 * L * (2 * M * D * 2 + 8 * M)
-    b_lb = 2 * L * (2 * M * D * (3 + (1 if training_dropout else 0)) + 8 * M)
+    b_lb = ln_bwd_launches * (2 * M * D * (3 + (1 if training_dropout else 0)) + 8 * M)
     return {
         "gemm_nt": dict(bytes=b_nt, flops=f_nt, launches=len(nt)),
         "wgrad": dict(bytes=b_wg, flops=f_wg, launches=len(wg)),
         "attn_fwd": dict(bytes=b_af, flops=f_af, launches=L),
         "attn_bwd": dict(bytes=b_ab, flops=f_ab, launches=L),
         "ln_fwd": dict(bytes=b_lf, flops=0, launches=0 if fused_ln else 2 * L),
-        "ln_bwd": dict(bytes=b_lb, flops=0, launches=2 * L),
+        "ln_bwd": dict(bytes=b_lb, flops=0, launches=ln_bwd_launches),
     }
 
 
@@ -256,7 +263,7 @@ def measure(a, config_id, dev, rank, world, steps, warmup, prof_steps, want_cpu)
         L.iq_prof_enable(0)
         per_step = {f: ms[i] / prof_steps for i, f in enumerate(FAMILIES)}
         fused_ln = int(cnt[FAMILIES.index("ln_fwd")]) == 0
-        work = family_work(geo, B, drop > 0, fused_ln)
+        work = family_work(geo, B, drop > 0, fused_ln, int(cnt[FAMILIES.index("ln_bwd")]) // prof_steps)
         dom = max(work, key=lambda f: per_step[f])
         w = work[dom]
         dur_ms = per_step[dom]

@@ -92,6 +92,20 @@ int iq_gemm_bf16_ln(const void* A, int lda, const void* W, int ldw, const float*
                     const iq_dropout_t* drop, const float* gamma, const float* beta, float eps, void* Z, void* X,
                     float* mean, float* rstd, int M, int D, int K, iq_stream_t stream);
 
+/* Data-gradient GEMM + the LayerNorm BACKWARD that consumes its result, in ONE launch (whole-row tiles, D in {128,192},
+ * K % 32 == 0, K >= 64):   dX = A[M,K] * Wt[D,K]^T + residual   (fp32, not stored), then exactly iq_ln_bwd on it:
+ *   dz = rstd * (g - mean_D(g) - xhat * mean_D(g * xhat)),  g = dX * gamma,  xhat = (z - mean) * rstd      bf16 [M,D]
+ *   dy = dropout_mask(dz) * scale (only when drop->p > 0)                                                   bf16 [M,D]
+ *   partial: iq_gemm_lnbwd_partial_rows(M) rows of [2*D] fp32 (dgamma | dbeta partial sums), to be reduced like
+ *   iq_ln_bwd's (iq_reduce_seg_t).
+ * The autograd backward of `x = norm(dropout(f(x)) + x)`, V/models/blocks/encoder_layer.py:24-25,32-33, behind the FFN1 /
+ * QKV data-gradient GEMM that feeds it.  All pointers 16-byte aligned. */
+int iq_gemm_lnbwd_supported(int D, int K);
+int iq_gemm_lnbwd_partial_rows(int M);
+int iq_gemm_bf16_lnbwd(const void* A, int lda, const void* Wt, int ldw, const void* residual, int ldr, const void* z,
+                       const float* mean, const float* rstd, const float* gamma, const iq_dropout_t* drop, void* dz,
+                       void* dy, float* partial, int M, int D, int K, iq_stream_t stream);
+
 /* Two chained NT GEMMs in one launch: H[M,F] = epi1(X[M,D] * Wa[F,D]^T); Y[M,D] = epi2(H * Wb[D,F]^T).
  * Replaces PositionwiseFeedForward.forward (V/models/layers/position_wise_feed_forward.py:12-17) + dropout2 + residual
  * (V/models/blocks/encoder_layer.py:30-33), and -- with the transposed weight shadows and epi1 = gate -- its data-gradient

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build-time check of the counted s_waitcnt vmcnt(N) waits that let the GEMM tails' global loads fly under the last
-operand stages (csrc/gemm_nt.hip, csrc/gemm_ln.hip).
+operand stages (csrc/gemm_nt.hip, csrc/gemm_ln.hip, csrc/gemm_lnbwd.hip).
 
 Those kernels wait for their last global_load_lds stage with `s_waitcnt vmcnt(EARLY)`, EARLY = the number of tail loads
 issued behind that stage.  That is only correct if the compiler emitted EXACTLY that many vector-memory loads between
@@ -50,33 +50,37 @@ def check(src, want_prefix):
     for name, body in kernels(isa(src)):
         if want_prefix not in name:
             continue
-        loads, drained = 0, False
+        loads, loads_bar, drained = 0, 0, False     # register loads since the block start / since the last s_barrier
         counted = []
         for idx, ln in enumerate(body):
             t = ln.strip()
-            if t.startswith("s_barrier") or re.match(r"\.LBB\d+_\d+:", t) or t.startswith(("s_cbranch", "s_branch")):
-                loads, drained = 0, False
-            elif re.match(r"(global_load_(dword|ubyte|ushort|short)|buffer_load_)", t) and "lds" not in t.split()[0]:
+            if t.startswith("s_barrier"):
+                loads, loads_bar, drained = 0, 0, False
+            elif re.match(r"\.LBB\d+_\d+:", t) or t.startswith(("s_cbranch", "s_branch")):
+                loads = 0           # (a forward branch around a wave-dependent MFMA block may sit between the loads and the wait)
+            elif t.startswith("global_load_lds"):
+                loads, loads_bar, drained = 0, 0, False      # loads issued before a DMA are OLDER than it: they do not count
+            elif re.match(r"(global_load_(dword|ubyte|ushort|short)|buffer_load_)", t):
                 loads += 1
+                loads_bar += 1
             else:
                 m = re.match(r"s_waitcnt vmcnt\((\d+)\)", t)
                 if m:
                     n = int(m.group(1))
                     nxt = [x.strip() for x in body[idx + 1: idx + 4]]
                     if n == 0:
-                        drained = loads > 0 or drained
-                        loads = 0 if not drained else loads
-                    elif (loads > 0 or drained) and any(x.startswith("s_barrier") for x in nxt):
-                        counted.append((n, loads, "drained" if drained else ""))
-                        if not drained and n > loads:
-                            problems.append(f"{name}: s_waitcnt vmcnt({n}) + s_barrier behind only {loads} register loads: "
+                        drained = loads_bar > 0 or drained
+                    elif (loads_bar > 0 or drained) and any(x.startswith("s_barrier") for x in nxt):
+                        have = max(loads, loads_bar)
+                        counted.append((n, have, "drained" if drained else ""))
+                        if not drained and n > have:
+                            problems.append(f"{name}: s_waitcnt vmcnt({n}) + s_barrier behind only {have} register loads: "
                                             "the last operand stage may not have landed")
-                        elif drained or n != loads:
-                            notes.append(f"{name}: tail wait vmcnt({n}) with {loads} loads{' after a full drain' if drained else ''} (safe, not overlapped)")
-                        loads, drained = 0, False
+                        elif drained or n != have:
+                            notes.append(f"{name}: tail wait vmcnt({n}) with {have} loads{' after a full drain' if drained else ''} (safe, not fully overlapped)")
         seen += 1
         m_epi = re.search(r"gemm_nt_async_kernelILi\d+ELi\d+ELi(\d+)ELb0", name)
-        expects = "gemm_ln_kernel" in name or (m_epi and int(m_epi.group(1)) & (1 | 2))    # residual / gate tails
+        expects = "gemm_ln_kernel" in name or "gemm_lnbwd_kernel" in name or (m_epi and int(m_epi.group(1)) & (1 | 2))    # residual / gate tails
         if expects and not counted:
             problems.append(f"{name}: no counted tail wait found")
         print(f"{name[:90]:90s} counted tail waits {counted}")
@@ -87,7 +91,8 @@ def check(src, want_prefix):
 
 def main():
     total, problems = 0, []
-    for src, pref in (("gemm_nt.hip", "Lb0EEEv10GemmParams"), ("gemm_ln.hip", "gemm_ln_kernel")):      # Lb0 = the non-RESK instantiations
+    for src, pref in (("gemm_nt.hip", "Lb0EEEv10GemmParams"), ("gemm_ln.hip", "gemm_ln_kernel"),      # Lb0 = the non-RESK instantiations
+                      ("gemm_lnbwd.hip", "gemm_lnbwd_kernel")):
         n, pr = check(src, pref)
         total += n
         problems += pr

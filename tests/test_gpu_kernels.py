@@ -222,6 +222,65 @@ def test_gemm_with_fused_layernorm_tail_equals_gemm_then_layernorm(L, D, K, M, p
         close_f32(rstd1, (1 / torch.sqrt(var + 1e-12)).squeeze(-1), "rstd", 1e-5)
 
 
+@pytest.mark.parametrize("D,K", [(192, 768), (192, 576), (128, 1024), (128, 384), (128, 64)])
+@pytest.mark.parametrize("M,pdrop", [(1000, 0.0), (50432, 0.1), (130, 0.25), (77, 0.0)])
+def test_dgrad_with_fused_layernorm_backward_equals_gemm_then_ln_bwd(L, D, K, M, pdrop):
+    """iq_gemm_bf16_lnbwd (FFN1 / QKV data gradient + residual + the LayerNorm backward that consumes it, one launch)
+    against the two launches it replaces (iq_gemm_bf16_nt with the residual, then iq_ln_bwd): dZ and dY bit for bit
+    (the rounded dX tile crosses LDS instead of HBM, same arithmetic order), gamma / beta gradients after their
+    fixed-order reduction to fp32 summation order; and against fp64 torch autograd of LayerNorm."""
+    N = _N()
+    assert L.iq_gemm_lnbwd_supported(D, K) == 1 and L.iq_gemm_lnbwd_supported(256, 256) == 0
+    g = torch.Generator(device="cuda").manual_seed(M + D + K)
+    A = bf(torch.randn(M, K, device=dev(), generator=g))
+    W = bf(torch.randn(D, K, device=dev(), generator=g) / math.sqrt(K))
+    R = bf(torch.randn(M, D, device=dev(), generator=g))
+    z = bf(torch.randn(M, D, device=dev(), generator=g) * 1.5 + 0.3)
+    gamma = torch.rand(D, device=dev(), generator=g) + 0.5
+    zf = z.float()
+    mean = zf.mean(-1).contiguous()
+    rstd = (1.0 / torch.sqrt(zf.var(-1, unbiased=False) + 1e-12)).contiguous()
+    dr = _drop(4321, 5, 7, pdrop)
+    # two launches
+    dx = run_gemm(L, A, W, M, D, K, residual=R, ldr=D)
+    dz0 = torch.empty_like(z); dy0 = torch.zeros_like(z)
+    dg0 = torch.empty(D, device=dev()); db0 = torch.empty(D, device=dev())
+    ws0 = torch.empty(L.iq_ln_bwd_ws_bytes(D), dtype=torch.uint8, device=dev())
+    N.check(L.iq_ln_bwd(dx.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), dz0.data_ptr(),
+                        dy0.data_ptr(), C.byref(dr) if pdrop > 0 else None, dg0.data_ptr(), db0.data_ptr(), ws0.data_ptr(), 0,
+                        M, D, stream()), "ln_bwd")
+    # fused
+    dz1 = torch.full_like(z, float("nan")); dy1 = torch.zeros_like(z)
+    rows = L.iq_gemm_lnbwd_partial_rows(M)
+    assert rows == (M + 127) // 128
+    part = torch.full((rows, 2 * D), float("nan"), device=dev())
+    N.check(L.iq_gemm_bf16_lnbwd(A.data_ptr(), K, W.data_ptr(), K, R.data_ptr(), D, z.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                 gamma.data_ptr(), C.byref(dr) if pdrop > 0 else None, dz1.data_ptr(), dy1.data_ptr(),
+                                 part.data_ptr(), M, D, K, stream()), "gemm_lnbwd")
+    def same(a, b, what):
+        if K >= 384:        # both paths add the residual inside the MFMA (gemm_nt's RESK tile): bit for bit
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16)), f"{what} differs from the two-launch path"
+        else:               # the unfused GEMM adds it in the VALU epilogue: a handful of dX elements round the other way at a tie
+            rows_off = (a.view(torch.int16) != b.view(torch.int16)).any(1).float().mean().item()
+            assert rows_off < 2e-3 and (a.float() - b.float()).abs().max().item() <= 2 ** -6 * a.float().abs().max().item(), (what, rows_off)
+    same(dz0, dz1, "dZ")
+    if pdrop > 0:
+        same(dy0, dy1, "dY")
+        kept = (dy1.float() != 0).float().mean().item() / max((dz1.float() != 0).float().mean().item(), 1e-9)
+        assert abs(kept - (1 - pdrop)) < 0.02
+    dg1, db1 = part[:, :D].sum(0), part[:, D:].sum(0)
+    close_f32(dg1, dg0, "dgamma", 1e-4)
+    close_f32(db1, db0, "dbeta", 1e-4)
+    # against autograd of the LayerNorm itself (fp64) on the same rounded dX
+    zz = z.double().requires_grad_(True)
+    gg = gamma.double().requires_grad_(True)
+    mu = zz.mean(-1, keepdim=True); var = zz.var(-1, unbiased=False, keepdim=True)
+    y = gg * ((zz - mu) / torch.sqrt(var + 1e-12))
+    y.backward(dx.double())
+    close_bf16(dz1, zz.grad, "dZ vs fp64 autograd", abs_=2e-2 * zz.grad.abs().max().item())
+    close_f32(dg1, gg.grad, "dgamma vs fp64", 5e-3)
+
+
 def _epi(N, **kw):
     e = N.Epilogue()
     for k, v in kw.items():

@@ -558,6 +558,12 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
   // profiles/r01_probes.txt: the launch on a side stream with a workgroup budget next to the following layer's chain
   // 6.57-7.29 vs 6.58 ms/step; each weight gradient right after its data-gradient GEMM 6.35 vs 6.15-6.22; the FFN
   // data-gradient pair as one chained launch 6.65-6.68 vs 6.62-6.64.)
+  // LayerNorm backward rides in the epilogue of the GEMM that produces its incoming gradient where a workgroup owns
+  // whole rows (D = 128 | 192): norm1's in the FFN1 data gradient of the same layer, norm2's in the QKV data gradient of
+  // the layer ABOVE (the top layer's comes from the head and keeps the stand-alone kernel).
+  const bool fuse1 = iq_gemm_lnbwd_supported(D, F) != 0, fuse2 = iq_gemm_lnbwd_supported(D, 3 * D) != 0;
+  const size_t ln_ws_need = (size_t)iq_gemm_lnbwd_partial_rows(M) * 2 * D * sizeof(float);
+  if ((fuse1 || fuse2) && ln_ws_need > iq_ln_bwd_ws_bytes(D)) return fail(m, IQ_ERR_UNSUPPORTED, "backward: batch too large for the LayerNorm partial rows");
   for (int sidx = (stage_hi > Lr ? Lr : stage_hi); sidx >= 1 && sidx >= stage_lo; --sidx) {
     const int l = sidx - 1;
     const LayerOff& o = m->L[l];
@@ -566,12 +572,15 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
     unsigned char *gZ = ws + w.gZ, *gY = ws + w.gY, *gZ1 = ws + w.gZ1, *gY1 = ws + w.gY1;
     unsigned char *gH = ws + w.gH, *gQKV = ws + w.gQKV;
     iq_epilogue_t e;
-    // norm2 backward (+ regenerated dropout2 mask)
-    const iq_dropout_t dr2 = m->bwd_site(3 + 3 * l, step_dev, tr);
     float* lp2 = (float*)(ws + w.ln_part[0]);
     float* lp1 = (float*)(ws + w.ln_part[1]);
-    IQ_TRY(iq_ln_bwd(ws + w.gA, ws + a.z2, (const float*)(ws + a.mean2), (const float*)(ws + a.rstd2), P + o.g2,
-                     gZ, gY, &dr2, nullptr, nullptr, lp2, accumulate, M, D, stream), "norm2 bwd");
+    // norm2 backward (+ regenerated dropout2 mask) -- unless the layer above already did it in its QKV data gradient
+    const bool norm2_here = l == Lr - 1 || !fuse2;
+    if (norm2_here) {
+      const iq_dropout_t dr2 = m->bwd_site(3 + 3 * l, step_dev, tr);
+      IQ_TRY(iq_ln_bwd(ws + w.gA, ws + a.z2, (const float*)(ws + a.mean2), (const float*)(ws + a.rstd2), P + o.g2,
+                       gZ, gY, &dr2, nullptr, nullptr, lp2, accumulate, M, D, stream), "norm2 bwd");
+    }
     const unsigned char* dO2 = tr ? gY : gZ;
     const unsigned char* dAo = tr ? gY1 : gZ1;
     const iq_wgrad_problem_t wg[4] = {
@@ -580,25 +589,42 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
         {dAo, D, ws + a.att, D, G + o.wo, G + o.bo, D, D},            // attention.w_concat
         {gQKV, 3 * D, xin, D, G + o.wqkv, G + o.bqkv, 3 * D, D}};     // attention.w_q|w_k|w_v
     // the LayerNorm gamma/beta partial rows of this layer ride on the same reduce launch
-    const int lrows = iq_ln_bwd_partial_rows(M, D);
-    const iq_reduce_seg_t lnseg[4] = {{lp2, lrows, 2L * D, G + o.g2, D}, {lp2 + D, lrows, 2L * D, G + o.be2, D},
-                                      {lp1, lrows, 2L * D, G + o.g1, D}, {lp1 + D, lrows, 2L * D, G + o.be1, D}};
+    const int rows2 = norm2_here ? iq_ln_bwd_partial_rows(M, D) : iq_gemm_lnbwd_partial_rows(M);
+    const int rows1 = fuse1 ? iq_gemm_lnbwd_partial_rows(M) : iq_ln_bwd_partial_rows(M, D);
+    const iq_reduce_seg_t lnseg[4] = {{lp2, rows2, 2L * D, G + o.g2, D}, {lp2 + D, rows2, 2L * D, G + o.be2, D},
+                                      {lp1, rows1, 2L * D, G + o.g1, D}, {lp1 + D, rows1, 2L * D, G + o.be1, D}};
     memset(&e, 0, sizeof(e));
     e.gate = ws + a.hid; e.ldg = F; e.gate_scale = dscale;
     IQ_TRY(iq_gemm_bf16_nt(dO2, D, m->sht(o.t_w2), D, gH, F, M, F, D, &e, stream), "ffn2 dgrad");
-    memset(&e, 0, sizeof(e));
-    e.residual = gZ; e.ldr = D;
-    IQ_TRY(iq_gemm_bf16_nt(gH, F, m->sht(o.t_w1), F, ws + w.gB, D, M, D, F, &e, stream), "ffn1 dgrad");
-    // norm1 backward (+ dropout1 mask)
+    // FFN1 data gradient (+ the residual-path gradient gZ) and norm1 backward (+ dropout1 mask)
     const iq_dropout_t dr1 = m->bwd_site(1 + 3 * l, step_dev, tr);
-    IQ_TRY(iq_ln_bwd(ws + w.gB, ws + a.z1, (const float*)(ws + a.mean1), (const float*)(ws + a.rstd1), P + o.g1,
-                     gZ1, gY1, &dr1, nullptr, nullptr, lp1, accumulate, M, D, stream), "norm1 bwd");
+    if (fuse1) {
+      IQ_TRY(iq_gemm_bf16_lnbwd(gH, F, m->sht(o.t_w1), F, gZ, D, ws + a.z1, (const float*)(ws + a.mean1),
+                                (const float*)(ws + a.rstd1), P + o.g1, &dr1, gZ1, gY1, lp1, M, D, F, stream), "ffn1 dgrad + norm1 bwd");
+    } else {
+      memset(&e, 0, sizeof(e));
+      e.residual = gZ; e.ldr = D;
+      IQ_TRY(iq_gemm_bf16_nt(gH, F, m->sht(o.t_w1), F, ws + w.gB, D, M, D, F, &e, stream), "ffn1 dgrad");
+      IQ_TRY(iq_ln_bwd(ws + w.gB, ws + a.z1, (const float*)(ws + a.mean1), (const float*)(ws + a.rstd1), P + o.g1,
+                       gZ1, gY1, &dr1, nullptr, nullptr, lp1, accumulate, M, D, stream), "norm1 bwd");
+    }
     IQ_TRY(iq_gemm_bf16_nt(dAo, D, m->sht(o.t_wo), D, ws + w.gAtt, D, M, D, D, nullptr, stream), "out-proj dgrad");
     IQ_TRY(iq_attn_bwd(ws + a.qkv, ws + a.att, ws + w.gAtt, (const float*)(ws + a.lse), gQKV, B, S, H, m->dh, stream), "attention bwd");
-    memset(&e, 0, sizeof(e));
-    e.residual = gZ1; e.ldr = D;
-    IQ_TRY(iq_gemm_bf16_nt(gQKV, 3 * D, m->sht(o.t_wqkv), 3 * D, ws + w.gA, D, M, D, 3 * D, &e, stream), "qkv dgrad");
+    // The four weight gradients of the layer, BEFORE the QKV data gradient: fused with the norm2 backward of the layer
+    // below, that GEMM overwrites gZ / gY and the norm2 partial rows, which the weight gradients / their reduce still read.
     IQ_TRY(iq_gemm_bf16_wgrad_grouped(wg, 4, M, wws, w.wgrad_ws_bytes, accumulate, 0, lnseg, 4, stream), "layer weight gradients");
+    if (l > 0 && fuse2) {
+      const LayerOff& ob = m->L[l - 1];
+      const WsPlan::L& ab = w.layers[l - 1];
+      const iq_dropout_t dr2b = m->bwd_site(3 + 3 * (l - 1), step_dev, tr);
+      IQ_TRY(iq_gemm_bf16_lnbwd(gQKV, 3 * D, m->sht(o.t_wqkv), 3 * D, gZ1, D, ws + ab.z2, (const float*)(ws + ab.mean2),
+                                (const float*)(ws + ab.rstd2), P + ob.g2, &dr2b, gZ, gY, lp2, M, D, 3 * D, stream),
+             "qkv dgrad + norm2 bwd of the layer below");
+    } else {
+      memset(&e, 0, sizeof(e));
+      e.residual = gZ1; e.ldr = D;
+      IQ_TRY(iq_gemm_bf16_nt(gQKV, 3 * D, m->sht(o.t_wqkv), 3 * D, ws + w.gA, D, M, D, 3 * D, &e, stream), "qkv dgrad");
+    }
   }
   if (stage_lo == 0) {
     const iq_dropout_t dr0 = m->bwd_site(0, step_dev, tr);
