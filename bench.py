@@ -93,7 +93,7 @@ def family_work(g, B, training_dropout, fused_ln, ln_bwd_launches):
     fused_bwd = 2 * L - ln_bwd_launches            # LayerNorm backwards inside a data-gradient GEMM
     dy = 1 if training_dropout else 0
     for l in range(L):
-        f1 = 1 if fused_bwd >= 2 * L - 1 or (fused_bwd > 0 and False) else 0     # norm1 backward in the FFN1 data gradient
+        f1 = 1 if fused_bwd >= 2 * L - 1 else 0                                  # norm1 backward in the FFN1 data gradient
         f2 = 1 if fused_bwd >= 2 * L - 1 and l > 0 else 0                        # norm2 backward of layer l-1 in layer l's QKV data gradient
         nt += [(M, 3 * D, D, 0, 0), (M, D, D, 1, ln_out), (M, F, D, 0, 0), (M, D, F, 1, ln_out)]   # fwd: qkv, out(+res), ffn1, ffn2(+res)
         nt += [(M, F, D, 1, 0), (M, D, F, 1 + f1, f1 * dy), (M, D, D, 0, 0), (M, D, 3 * D, 1 + f2, f2 * dy)]   # dgrad: ffn2(+gate), ffn1(+res), out, qkv(+res)
