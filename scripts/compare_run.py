@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--frames", type=int, default=6000)
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
-    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--lr", type=float, default=2e-4, help="1e-3 collapses both post-norm stacks to one class (measured)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--small", action="store_true", help="2-layer d64 models (tests)")
     a = ap.parse_args()

@@ -616,6 +616,32 @@ def test_attention_peaked_softmax_is_stable(L):
     close_f32(lse, lref, "lse", 2e-3)
 
 
+@pytest.mark.parametrize("S,H,dh", [(197, 3, 64), (65, 8, 16), (300, 2, 32)])
+def test_attention_deferred_rescale_branch(L, S, H, dh):
+    """The forward raises its running maximum (and rescales the output accumulators) only when a key block's maximum
+    exceeds it by more than 2^8: a data-dependent, rarely taken branch.  Force it late: one key of the LAST block
+    matches one query row so strongly that the maximum jumps by far more than the threshold there -- and, in another
+    frame, a spike in the FIRST block that no later block exceeds (no raise after block 0)."""
+    N = _N()
+    Bf, D = 3, H * dh
+    g = torch.Generator(device="cuda").manual_seed(S + dh)
+    qkv = torch.randn(Bf * S, 3 * D, device=dev(), generator=g)
+    qkv[0 * S + 5, D + 0 * dh: D + 1 * dh] *= 0                                  # frame 0, head 0: key S-3 := 4 q_5
+    qkv[0 * S + (S - 3), D: D + dh] = 4.0 * qkv[0 * S + 5, 0:dh]
+    qkv[1 * S + 2, D: D + dh] = 4.0 * qkv[1 * S + 40, 0:dh]                       # frame 1, head 0: key 2 := 4 q_40
+    qkv = bf(qkv)
+    out = torch.empty(Bf * S, D, dtype=torch.bfloat16, device=dev())
+    lse = torch.empty(Bf, H, S, device=dev())
+    N.check(L.iq_attn_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), Bf, S, H, dh, stream()), "attn_fwd")
+    oref, lref = attn_ref(qkv.double(), Bf, S, H, dh)
+    assert torch.isfinite(out.float()).all()
+    close_bf16(out, oref, "deferred rescale", rel=2 ** -6, abs_=0.03)
+    close_f32(lse, lref, "lse", 2e-3)
+    # the spiked rows really are peaked (the branch was exercised): their output is essentially one value row
+    v_row = qkv[0 * S + (S - 3), 2 * D: 2 * D + dh].float()
+    assert (out[0 * S + 5, 0:dh].float() - v_row).abs().max().item() < 0.05 * v_row.abs().max().item() + 0.02
+
+
 def test_attention_limits(L):
     assert L.iq_attn_supported(197, 64) == 1
     assert L.iq_attn_supported(1025, 16) == 1
