@@ -87,6 +87,38 @@ __device__ __forceinline__ void stage_rows(bf16* img, const bf16* base, long ldg
   }
 }
 
+// Two images at once, loads batched: every thread first REQUESTS UN 16-byte chunks of each image (2 UN loads in flight),
+// then writes them.  stage_rows alone compiles to load -> s_waitcnt vmcnt(0) -> ds_write per trip (not unrolled: the trip
+// count is a run-time value), i.e. 3.5 serialised memory round trips per image at S = 197: waves spend ~45 % of their
+// cycles in s_waitcnt / s_barrier (SQ_WAIT_ANY, profiles/r02_pmc_attn_*.txt).  Loads are unconditional from clamped rows
+// (a predicated load is merged with its zero fill at once, i.e. waited for); rows past S are zeroed when written.
+template <int DH, int UN>
+__device__ __forceinline__ void stage_pair(bf16* imgA, const bf16* baseA, long ldgA, bf16* imgB, const bf16* baseB, long ldgB,
+                                           int r_begin, int nrows_pad, int S, int tid) {
+  constexpr int CPR = AttCfg<DH>::CPR, LD = AttCfg<DH>::LD;
+  const int total = nrows_pad * CPR;
+  for (int base = 0; base < total; base += UN * ATT_THREADS) {
+    bf16x8 va[UN], vb[UN];
+#pragma unroll
+    for (int j = 0; j < UN; ++j) {
+      const int id = min(base + j * ATT_THREADS + tid, total - 1);
+      const int r = min(r_begin + id / CPR, S - 1), c = id % CPR;
+      va[j] = *reinterpret_cast<const bf16x8*>(baseA + (long)r * ldgA + c * 8);
+      vb[j] = *reinterpret_cast<const bf16x8*>(baseB + (long)r * ldgB + c * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < UN; ++j) {
+      const int id = base + j * ATT_THREADS + tid;
+      const int r = id / CPR, c = id % CPR;
+      if (id < total) {
+        const bool live = r_begin + r < S;
+        *reinterpret_cast<bf16x8*>(imgA + r * LD + c * 8) = live ? va[j] : bf16x8{};
+        *reinterpret_cast<bf16x8*>(imgB + r * LD + c * 8) = live ? vb[j] : bf16x8{};
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ bf16x8 pack_b(const f32x4& lo, const f32x4& hi) {
   bf16x8 v;
 #pragma unroll
@@ -128,6 +160,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16* __res
   const uint8_t* mk = MASKED ? mask + (long)b * (mask_hstride ? (long)H * S * S : (long)S * S) + h * mask_hstride : nullptr;
   const int qtiles = (S + 31) / 32, npass = (qtiles + ATT_WAVES - 1) / ATT_WAVES, nstage = (S + kchunk - 1) / kchunk;
 
+  if (nstage == 1) {            // the whole sequence fits one stage: fill it first, while no accumulator is live
+    stage_pair<DH, 4>(Ks, kb_, ldg, Vs, vb_, ldg, 0, min(kchunk, ((S + 31) / 32) * 32), S, tid);
+    __syncthreads();
+  }
   for (int pass = 0; pass < npass; ++pass) {
     const int qt = pass * ATT_WAVES + wave;
     const bool active = qt < qtiles;
@@ -145,10 +181,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16* __res
     for (int st = 0; st < nstage; ++st) {
       const int k0 = st * kchunk;
       const int krows = min(kchunk, ((S - k0 + 31) / 32) * 32);
-      if (nstage > 1 || pass == 0) {
+      if (nstage > 1) {
         __syncthreads();
-        stage_rows<DH>(Ks, kb_, ldg, k0, krows, S, tid);
-        stage_rows<DH>(Vs, vb_, ldg, k0, krows, S, tid);
+        stage_pair<DH, 2>(Ks, kb_, ldg, Vs, vb_, ldg, k0, krows, S, tid);
         __syncthreads();
       }
       if (active) {
@@ -270,8 +305,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const bf16* __
 
   // ---- delta[q] = sum_d dO*O; lse ---------------------------------------------------------------
   if (single) {
-    stage_rows<DH>(I0, qb, ldg, 0, spad, S, tid);
-    stage_rows<DH>(I1, dob, (long)D, 0, spad, S, tid);
+    stage_pair<DH, 4>(I0, qb, ldg, I1, dob, (long)D, 0, spad, S, tid);
     __syncthreads();
   }
   // single chunk: delta from the dO image just staged (dO is fetched from HBM once, not twice); O comes from HBM, its only use
@@ -316,8 +350,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const bf16* __
       const int rows = min(chunk, spad - q0);
       if (!single) {
         __syncthreads();
-        stage_rows<DH>(I0, qb, ldg, q0, rows, S, tid);
-        stage_rows<DH>(I1, dob, (long)D, q0, rows, S, tid);
+        stage_pair<DH, 2>(I0, qb, ldg, I1, dob, (long)D, q0, rows, S, tid);
         __syncthreads();
       }
       if (!have) continue;
@@ -411,8 +444,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const bf16* __
       const int rows = min(chunk, spad - k0);
       if (!single || qg == 0) {
         __syncthreads();
-        stage_rows<DH>(I0, kb_, ldg, k0, rows, S, tid);
-        stage_rows<DH>(I1, vb_, ldg, k0, rows, S, tid);
+        stage_pair<DH, 2>(I0, kb_, ldg, I1, vb_, ldg, k0, rows, S, tid);
         __syncthreads();
       }
       if (!have) continue;
