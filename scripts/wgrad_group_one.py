@@ -20,12 +20,12 @@ for i, (n, k) in enumerate(shapes):
 nb = L.iq_wgrad_grouped_ws_bytes(probs, 4, M, budget); ws = torch.empty(nb, dtype=torch.uint8, device=d)
 st = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
-    L.iq_gemm_bf16_wgrad_grouped(probs, 4, M, ws.data_ptr(), nb, 0, budget, st)
+    L.iq_gemm_bf16_wgrad_grouped(probs, 4, M, ws.data_ptr(), nb, 0, budget, None, 0, st)
 torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record()
 for _ in range(reps):
-    L.iq_gemm_bf16_wgrad_grouped(probs, 4, M, ws.data_ptr(), nb, 0, budget, st)
+    L.iq_gemm_bf16_wgrad_grouped(probs, 4, M, ws.data_ptr(), nb, 0, budget, None, 0, st)
 b.record(); torch.cuda.synchronize()
 us = a.elapsed_time(b) / reps * 1e3
 print(f"grouped layer wgrad: {us:.1f} us  algorithmic {byt / 1e6:.1f} MB -> {byt / us / 1e3:.0f} GB/s  slab ws {nb / 1e6:.1f} MB")

@@ -192,9 +192,15 @@ __global__ __launch_bounds__(WG_THREADS, 4) void wgrad_kernel(const WgradParams 
 // every wave owns the WHOLE 64x64 output tile for its own 32-row stages of the split (stage s -> wave s mod 4), stages
 // its rows through a private LDS area only to transpose them (ds_read_b64_tr_b16), 0.5 fragments per MFMA, and the
 // waves free-run; the four accumulator sets meet once, through LDS, when the split is done.
-constexpr int PW_THREADS = 256, PW_T = 64, PW_LD = PW_T + 16, PW_ROWS = 32;
-constexpr int PW_WAVE_LDS = 2 * PW_ROWS * PW_LD;   // elements: Y stage + X stage
-constexpr int PW_RED_LD = PW_T + 4;                // padded fp32 row of the final cross-wave sum
+// Round 2: the wave's tile is 64 x 64, 128 x 64 or 64 x 128 (n x k), chosen per problem along its wider side.  The
+// kernel moves its operands at the L2-level rate the chip gives this access shape (~14.5 TB/s: 8 waves x 16 KB in
+// flight measured the same as 12 x 8 KB), so the lever is bytes per flop: a 64 x 64 tile loads 256 B per contraction row
+// for 8192 flop, a 128 x 64 tile 384 B for 16384 (0.75 x), and the layer's launch moves 1.10 GB instead of 1.39 GB.
+constexpr int PW_THREADS = 256, PW_T = 64, PW_ROWS = 32;
+constexpr int PW_MAXW = 128;                        // widest tile side
+constexpr int pw_ld(int t) { return t + 16; }       // padded LDS row (elements): conflict-free transposing reads
+constexpr int PW_WAVE_LDS = PW_ROWS * (pw_ld(PW_MAXW) + pw_ld(PW_T));   // elements per wave: widest Y stage + X stage
+constexpr int PW_RED_ROWS = 16;                     // n-rows of the final cross-wave sum per pass
 
 // A launch covers up to PW_MAXP problems that share M (the four Linear layers of one encoder layer): the grid is
 // (all their tiles) x (M splits), so one pipeline fill / drain and one slab reduce serve the whole layer.
@@ -204,6 +210,7 @@ struct PwProb {
   float* slab;       // [splits][N*K]
   float* bslab;      // [splits][N] or null
   int ldy, ldx, N, K, tiles_n, tiles_k, tile0;
+  int tn, tk;        // the wave tile of this problem: 64 x 64, 128 x 64 or 64 x 128
 };
 struct PwGroup {
   PwProb pr[PW_MAXP];
@@ -213,113 +220,111 @@ struct PwGroup {
 #endif
 };
 
-__global__ __launch_bounds__(PW_THREADS, 3) void wgrad_pw_kernel(const PwGroup g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+template <int TN, int TK>
+__device__ __forceinline__ void pw_body(const PwGroup& g, const PwProb& p, int tile, int split, unsigned char* smem) {
+  constexpr int NI = TN / 16, NJ = TK / 16;            // 16 x 16 accumulator tiles
+  constexpr int LDY = pw_ld(TN), LDX = pw_ld(TK);
+  constexpr int YC = TN / 64, XC = TK / 64;            // 64-column load groups per row
+  constexpr int RED_LD = TK + 4;                       // padded fp32 row of the final cross-wave sum
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   bf16* Ys = reinterpret_cast<bf16*>(smem) + wave * PW_WAVE_LDS;
-  bf16* Xs = Ys + PW_ROWS * PW_LD;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);   // the tiles of one split are neighbours on one XCD: re-reads hit its L2
-  const int split = lid / g.ntile, gt = lid % g.ntile;
-  PwProb p = g.pr[0];
-#pragma unroll
-  for (int i = 1; i < PW_MAXP; ++i)
-    if (i < g.nprob && gt >= g.pr[i].tile0) p = g.pr[i];
-  const int tile = gt - p.tile0;
+  bf16* Xs = Ys + PW_ROWS * LDY;
   // Tiles run along the LONGER side of the output first: where consecutive workgroups spill over to the next XCD the
   // cut then separates blocks of the wide operand, and only the narrow one is fetched by both L2s.
   int nt, kt;
   if (p.tiles_n >= p.tiles_k) { nt = tile / p.tiles_k; kt = tile % p.tiles_k; }
   else { kt = tile / p.tiles_n; nt = tile % p.tiles_n; }
-  const int n0 = nt * PW_T, k0 = kt * PW_T;
+  const int n0 = nt * TN, k0 = kt * TK;
   const int mbeg = split * g.rows_per_split;
   const int mend = min(g.M, mbeg + g.rows_per_split);
   const bool do_bias = p.bslab != nullptr && kt == 0;
 
-  f32x4 acc[4][4], accb[4];
+  f32x4 acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  bf16x8 ones;
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias gradient = column sums of dY: accumulated by the VALU from the staged rows, 8 columns per lane and 64-column
+  // group (round 1 spent one extra MFMA accumulator tile per 16 columns on it: 32 registers at TN = 128, which spilled)
+  float bs[YC][8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+  for (int c = 0; c < YC; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs[c][e] = 0.f;
 
   // a load instruction covers 8 rows x 128 B; the 16-lane groups of the LDS write pair rows r and r+4, whose
-  // 160 B-strided images fall on disjoint bank halves
+  // padded images fall on disjoint bank halves
   const int prow = ((lane >> 4) & 3) + ((lane >> 3) & 1) * 4, pch = lane & 7;
   // columns past N / K only feed accumulator rows / columns that are never stored: point them at column 0 instead
   // of predicating the loads.  Rows past the split end must contribute zero (only a split's last stage can be partial).
-  const bf16* yptr = p.Y + (long)prow * p.ldy + (n0 + pch * 8 < p.N ? n0 + pch * 8 : 0);
-  const bf16* xptr = p.X + (long)prow * p.ldx + (k0 + pch * 8 < p.K ? k0 + pch * 8 : 0);
+  const bf16* yptr[YC];
+  const bf16* xptr[XC];
+#pragma unroll
+  for (int c = 0; c < YC; ++c) { const int col = n0 + c * 64 + pch * 8; yptr[c] = p.Y + (long)prow * p.ldy + (col < p.N ? col : 0); }
+#pragma unroll
+  for (int c = 0; c < XC; ++c) { const int col = k0 + c * 64 + pch * 8; xptr[c] = p.X + (long)prow * p.ldx + (col < p.K ? col : 0); }
   const long ystep = 8L * p.ldy, xstep = 8L * p.ldx;
-  bf16x8 ry[4], rx[4];
+  bf16x8 ry[YC][4], rx[XC][4];
   auto gload = [&](int m0) {
-    const bf16* yp = yptr + (long)m0 * p.ldy;
-    const bf16* xp = xptr + (long)m0 * p.ldx;
-    if (m0 + PW_ROWS <= mend) {           // wave-uniform
+    const bool full = m0 + PW_ROWS <= mend;           // wave-uniform
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        ry[j] = *reinterpret_cast<const bf16x8*>(yp + j * ystep);
-        rx[j] = *reinterpret_cast<const bf16x8*>(xp + j * xstep);
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = full || (m0 + j * 8 + prow < mend);
+#pragma unroll
+      for (int c = 0; c < YC; ++c) {
+        bf16x8 v = {};
+        if (ok) v = *reinterpret_cast<const bf16x8*>(yptr[c] + (long)m0 * p.ldy + j * ystep);
+        ry[c][j] = v;
       }
-    } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        bf16x8 vy = {}, vx = {};
-        if (m0 + j * 8 + prow < mend) {
-          vy = *reinterpret_cast<const bf16x8*>(yp + j * ystep);
-          vx = *reinterpret_cast<const bf16x8*>(xp + j * xstep);
-        }
-        ry[j] = vy; rx[j] = vx;
+      for (int c = 0; c < XC; ++c) {
+        bf16x8 v = {};
+        if (ok) v = *reinterpret_cast<const bf16x8*>(xptr[c] + (long)m0 * p.ldx + j * xstep);
+        rx[c][j] = v;
       }
     }
   };
   auto lstore = [&]() {
+    if (do_bias) {                                    // workgroup-uniform
+#pragma unroll
+      for (int c = 0; c < YC; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bs[c][e] += (float)ry[c][j][e];
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      *reinterpret_cast<bf16x8*>(Ys + (j * 8 + prow) * PW_LD + pch * 8) = ry[j];
-      *reinterpret_cast<bf16x8*>(Xs + (j * 8 + prow) * PW_LD + pch * 8) = rx[j];
+#pragma unroll
+      for (int c = 0; c < YC; ++c) *reinterpret_cast<bf16x8*>(Ys + (j * 8 + prow) * LDY + c * 64 + pch * 8) = ry[c][j];
+#pragma unroll
+      for (int c = 0; c < XC; ++c) *reinterpret_cast<bf16x8*>(Xs + (j * 8 + prow) * LDX + c * 64 + pch * 8) = rx[c][j];
     }
   };
 
-#ifdef IQ_WGRAD_STAMPS
-  unsigned long long tk_[6] = {0, 0, 0, 0, 0, 0}, tl_, tn_;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_) :: "memory");
-#endif
   int m = mbeg + wave * PW_ROWS, mnext = m + 4 * PW_ROWS;
   if (m < mend) {
     gload(m);
     lstore();
     if (mnext < mend) gload(mnext);
   }
-  IQ_WTICK(0);
   while (m < mend) {
     // LDS is in-order within a wave; only keep the compiler from moving reads across the writes of other lanes
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    bf16x8 af[4], bfr[4];
+    bf16x8 af[NI], bfr[NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = tr_frag(Ys, PW_LD, 0, i * 16, lane);
+    for (int i = 0; i < NI; ++i) af[i] = tr_frag(Ys, LDY, 0, i * 16, lane);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bfr[j] = tr_frag(Xs, PW_LD, 0, j * 16, lane);
+    for (int j = 0; j < NJ; ++j) bfr[j] = tr_frag(Xs, LDX, 0, j * 16, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    IQ_WTICK(1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NJ; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-      if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
-    }
-    IQ_WTICK(2);
-#ifdef IQ_WGRAD_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    IQ_WTICK(3);
-#endif
     m = mnext; mnext += 4 * PW_ROWS;
     // the stage lives in registers: its LDS image is overwritten (and the stage after it requested) while the MFMAs
     // above drain; a wave that finds its data late only stalls itself
@@ -327,53 +332,67 @@ __global__ __launch_bounds__(PW_THREADS, 3) void wgrad_pw_kernel(const PwGroup g
       lstore();
       if (mnext < mend) gload(mnext);
     }
-    IQ_WTICK(4);
   }
-#ifdef IQ_WGRAD_STAMPS
-  __syncthreads();
-  IQ_WTICK(5);
-  if (tid == 0 && g.stamps)
-    for (int i = 0; i < 6; ++i) g.stamps[(long)blockIdx.x * 6 + i] = tk_[i];
-#endif
 
-  // ---- sum the four waves' accumulators (two half tiles of 32 n-rows through LDS), write the slab ----------------
-  float* red = reinterpret_cast<float*>(smem);     // [4 waves][32][PW_RED_LD]
+  // ---- sum the four waves' accumulators (PW_RED_ROWS n-rows at a time through LDS), write the slab ----------------
+  float* red = reinterpret_cast<float*>(smem);     // [4 waves][PW_RED_ROWS][RED_LD]
   float* out = p.slab + (long)split * p.N * p.K;
+  static_assert(4 * PW_RED_ROWS * RED_LD * 4 <= 4 * PW_WAVE_LDS * 2, "the reduction area fits the stage areas");
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    __syncthreads();                               // stage areas (h = 0) / previous half (h = 1) no longer read
+  for (int h = 0; h < NI; ++h) {                   // one 16-row accumulator tile row per pass
+    __syncthreads();                               // stage areas (h = 0) / previous pass no longer read
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          red[(wave * 32 + ii * 16 + (lane >> 4) * 4 + r) * PW_RED_LD + j * 16 + (lane & 15)] = acc[h * 2 + ii][j][r];
+      for (int r = 0; r < 4; ++r)
+        red[(wave * PW_RED_ROWS + (lane >> 4) * 4 + r) * RED_LD + j * 16 + (lane & 15)] = acc[h][j][r];
     __syncthreads();
+    constexpr int F4 = PW_RED_ROWS * TK / 4;       // float4 per pass
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int id = tid + c * PW_THREADS;        // 512 float4 = 32 rows x 16
-      const int row = id >> 4, c4 = (id & 15) * 4;
-      f32x4 s = *reinterpret_cast<const f32x4*>(red + row * PW_RED_LD + c4);
+    for (int c = 0; c < (F4 + PW_THREADS - 1) / PW_THREADS; ++c) {
+      const int id = tid + c * PW_THREADS;
+      if (id < F4) {
+        const int row = id / (TK / 4), c4 = (id % (TK / 4)) * 4;
+        f32x4 sum = *reinterpret_cast<const f32x4*>(red + row * RED_LD + c4);
 #pragma unroll
-      for (int w = 1; w < 4; ++w) s += *reinterpret_cast<const f32x4*>(red + (w * 32 + row) * PW_RED_LD + c4);
-      const int n = n0 + h * 32 + row, k = k0 + c4;
-      if (n < p.N && k < p.K) *reinterpret_cast<f32x4*>(out + (long)n * p.K + k) = s;   // K % 8 == 0
+        for (int w = 1; w < 4; ++w) sum += *reinterpret_cast<const f32x4*>(red + (w * PW_RED_ROWS + row) * RED_LD + c4);
+        const int n = n0 + h * 16 + row, k = k0 + c4;
+        if (n < p.N && k < p.K) *reinterpret_cast<f32x4*>(out + (long)n * p.K + k) = sum;   // K % 8 == 0
+      }
     }
   }
   if (do_bias) {
     __syncthreads();
-    // accb: every column of the 16x16 result holds the same row sums; lane&15 == 0 publishes them
-    if ((lane & 15) == 0) {
+    // a lane's 8 columns were summed over its own rows (prow + 8 j of every stage): add the 8 lanes that share pch
+    // (lane bits 3, 4, 5), fixed order; the pch leaders publish
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int c = 0; c < YC; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave * 64 + i * 16 + (lane >> 4) * 4 + r] = accb[i][r];
-    }
+      for (int e = 0; e < 8; ++e) {
+        float v = bs[c][e];
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 8) red[wave * TN + c * 64 + pch * 8 + e] = v;
+      }
     __syncthreads();
-    if (tid < 64 && n0 + tid < p.N)
-      p.bslab[(long)split * p.N + n0 + tid] = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+    if (tid < TN && n0 + tid < p.N)
+      p.bslab[(long)split * p.N + n0 + tid] = red[tid] + red[TN + tid] + red[2 * TN + tid] + red[3 * TN + tid];
   }
+}
+
+__global__ __launch_bounds__(PW_THREADS, 2) void wgrad_pw_kernel(const PwGroup g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);   // the tiles of one split are neighbours on one XCD: re-reads hit its L2
+  const int split = lid / g.ntile, gt = lid % g.ntile;
+  PwProb p = g.pr[0];
+#pragma unroll
+  for (int i = 1; i < PW_MAXP; ++i)
+    if (i < g.nprob && gt >= g.pr[i].tile0) p = g.pr[i];
+  const int tile = gt - p.tile0;
+  if (p.tn == 128) pw_body<128, 64>(g, p, tile, split, smem);          // wave-uniform (a workgroup serves one problem)
+  else if (p.tk == 128) pw_body<64, 128>(g, p, tile, split, smem);
+  else pw_body<64, 64>(g, p, tile, split, smem);
 }
 
 // out[i] (+)= sum_s slab[s][i] for up to 2*PW_MAXP segments (weights and biases of a group) in ONE launch.
@@ -451,14 +470,24 @@ inline WgradPlan wgrad_plan(int M, int N, int K) {
 inline bool pw_eligible(int N, int K) { return (long)N * K <= 512 * 1024; }
 inline size_t pad4(size_t v) { return (v + 3) / 4 * 4; }
 
+// wave tile of a problem: 128 along the wider side when that side holds at least two such tiles, else 64 x 64
+inline void pw_tile(int N, int K, int* tn, int* tk) {
+  *tn = 64; *tk = 64;
+  if (N >= K && N >= 256) *tn = 128;
+  else if (K > N && K >= 256) *tk = 128;
+}
 struct PwPlan { int ntile, splits, rows_per_split; size_t floats; };
 inline PwPlan pw_plan(const iq_wgrad_problem_t* pr, int nprob, int M, int max_wgs) {
   PwPlan w;
   w.ntile = 0;
-  for (int i = 0; i < nprob; ++i) w.ntile += ((pr[i].N + PW_T - 1) / PW_T) * ((pr[i].K + PW_T - 1) / PW_T);
-  // three 4-wave workgroups per CU, filled once -- or the caller's smaller budget when the launch is meant to
-  // share the CUs with another stream's kernels
-  const int slots = (max_wgs > 0 && max_wgs < 768) ? max_wgs : 768;
+  for (int i = 0; i < nprob; ++i) {
+    int tn, tk;
+    pw_tile(pr[i].N, pr[i].K, &tn, &tk);
+    w.ntile += ((pr[i].N + tn - 1) / tn) * ((pr[i].K + tk - 1) / tk);
+  }
+  // two 4-wave workgroups per CU (a 128 x 64 wave tile holds 128 accumulator registers), filled once -- or the caller's
+  // smaller budget when the launch is meant to share the CUs with another stream's kernels
+  const int slots = (max_wgs > 0 && max_wgs < 512) ? max_wgs : 512;
   int splits = slots / w.ntile;
   const int max_splits = (M + 255) / 256;           // at least two stages per wave
   if (splits > max_splits) splits = max_splits;
@@ -604,8 +633,9 @@ extern "C" int iq_gemm_bf16_wgrad_grouped(const iq_wgrad_problem_t* probs, int n
     const iq_wgrad_problem_t& b = probs[i];
     PwProb& q = g.pr[i];
     q.Y = (const bf16*)b.dY; q.X = (const bf16*)b.X; q.ldy = b.ldy; q.ldx = b.ldx; q.N = b.N; q.K = b.K;
-    q.tiles_n = (b.N + PW_T - 1) / PW_T;
-    q.tiles_k = (b.K + PW_T - 1) / PW_T;
+    pw_tile(b.N, b.K, &q.tn, &q.tk);
+    q.tiles_n = (b.N + q.tn - 1) / q.tn;
+    q.tiles_k = (b.K + q.tk - 1) / q.tk;
     q.tile0 = tile0;
     tile0 += q.tiles_n * q.tiles_k;
     const long n = (long)b.N * b.K;
@@ -620,8 +650,8 @@ extern "C" int iq_gemm_bf16_wgrad_grouped(const iq_wgrad_problem_t* probs, int n
   }
   add_extra(rg, nblk);
   rg.accumulate = accumulate;
-  const size_t lds_pw = (size_t)4 * PW_WAVE_LDS * 2;   // 40 KiB >= 4 x 32 x PW_RED_LD x 4 B of the final sum
-  static_assert(4 * PW_WAVE_LDS * 2 >= 4 * 32 * PW_RED_LD * 4, "reduction area must fit the stage areas");
+  const size_t lds_pw = (size_t)4 * PW_WAVE_LDS * 2;   // 4 waves x 32 rows x (144 + 80) elements = 56 KiB
+  if (lds_pw > 48 * 1024) (void)hipFuncSetAttribute((const void*)wgrad_pw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pw);
   wgrad_pw_kernel<<<w.ntile * w.splits, PW_THREADS, lds_pw, st>>>(g);
   launch_reduce(rg, nblk, st);
   return iq_launch_status();
