@@ -147,9 +147,12 @@ def test_gemm_plain_and_bias_relu(L, M, N_, K):
     close_bf16(run_gemm(L, A, B, M, N_, K, bias=bias, relu=1), torch.relu(ref + bias.double()), "bias+relu")
 
 
-@pytest.mark.parametrize("M,N_,K", [(16384, 576, 192), (16384 + 77, 768, 192), (20000, 512, 128), (50432, 768, 192)])
+@pytest.mark.parametrize("M,N_,K", [(16384, 576, 192), (16384 + 77, 768, 192), (20000, 512, 128), (50432, 768, 192),
+                                    (50432, 576, 192), (50001, 768, 64), (100003, 512, 128), (41472 + 5, 320, 192),
+                                    (57344, 256, 160), (49664, 1024, 128), (49663, 1024, 128)])
 def test_gemm_wide_n_many_rows(L, M, N_, K):
-    """Wide N, K <= 192, many rows -- the cfg B FFN1 / QKV / FFN2-dgrad shapes: ragged M tail, strided A, bias+ReLU,
+    """Wide N, K <= 192, many rows -- the cfg B FFN1 / QKV / FFN2-dgrad shapes and their neighbours (half column tile at
+    N = 576 / 320, K = 64 / 128 / 160, 100 k rows): ragged M tail, strided A, bias+ReLU,
     gate, residual, and a dropout mask that depends only on (seed, step, site, element index), not on M."""
     g = torch.Generator(device="cuda").manual_seed(M + N_)
     Abig = bf(torch.randn(M, K + 8, device=dev(), generator=g))

@@ -438,7 +438,8 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
     return iq_launch_status();
   }
   // Variants that were measured and not kept (weight-stationary persistent workgroups, wave-private weight-in-registers
-  // waves, 64- / 256-row tiles, 192-column tiles with epilogue loads) live in scripts/dbg/variants/ with their numbers.
+  // waves, the A-stationary persistent row sweep with counted waits across tile boundaries, 64- / 256-row tiles, 192-column
+  // tiles with epilogue loads) live in scripts/dbg/variants/ with their numbers.
   const size_t lds_async = (size_t)3 * (bm + bn) * 32 * 2;     // ring of 3 stages
   const size_t lds_reg = (size_t)(BM + bn) * BK * 2;
 #define IQ_GEMM_LAUNCH(BN_, EPI_)                                                                  \
