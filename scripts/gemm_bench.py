@@ -37,6 +37,15 @@ def wg(N_, K):
     byt = 2 * (M * N_ + M * K) + 4 * N_ * K
     print(f"wgrad N={N_:5d} K={K:5d}: {us:8.1f} us  {byt/us/1e3:7.1f} GB/s  {2*M*N_*K/us/1e6:7.1f} TFLOP/s  (slab ws {nb/1e6:.1f} MB)")
 print(f"M = {M}")
+if len(sys.argv) > 4 and sys.argv[2] == "shape":      # python scripts/gemm_bench.py M shape N K [res|gate|bias ...]
+    fl = sys.argv[5:]
+    nt(int(sys.argv[3]), int(sys.argv[4]), bias="bias" in fl, relu="relu" in fl, drop=0.1 if "drop" in fl else 0.0, res="res" in fl, gate="gate" in fl)
+    sys.exit(0)
+if len(sys.argv) > 2 and sys.argv[2] == "big":        # ViT-Base shapes (M = 512 x 197 = 100864)
+    for (n_, k_, kw) in ((2304, 768, dict(bias=True)), (768, 768, dict(bias=True, drop=0.1, res=True)), (3072, 768, dict(bias=True, relu=True, drop=0.1)),
+                         (768, 3072, dict(bias=True, drop=0.1, res=True)), (3072, 768, dict(gate=True)), (768, 3072, dict(res=True)), (768, 2304, dict(res=True)), (768, 768, dict())):
+        nt(n_, k_, **kw)
+    sys.exit(0)
 if len(sys.argv) > 2:
     nt = wg = lambda *a, **k: None
 nt(576, 192, bias=True)

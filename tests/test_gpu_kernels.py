@@ -180,6 +180,36 @@ def test_gemm_wide_n_many_rows(L, M, N_, K):
     assert torch.equal((out_s.float() != 0)[sel], keep[:Ms][sel])
 
 
+@pytest.mark.parametrize("M,N_,K", [(50432, 768, 768), (40000 + 77, 1024, 256), (100864, 768, 3072), (35000, 2304, 768)])
+def test_gemm_big_tiles(L, M, N_, K):
+    """The MFMA-bound shapes (ViT-Base: D 768, F 3072, 512 frames x 197 tokens) run the persistent 256 x 256-tile kernel
+    (gemm_big.hip): every epilogue it serves, a ragged last row block, and the same dropout mask as the tiled kernel."""
+    g = torch.Generator(device="cuda").manual_seed(M + N_ + K)
+    A = bf(torch.randn(M, K, device=dev(), generator=g))
+    B = bf(torch.randn(N_, K, device=dev(), generator=g) / math.sqrt(K))
+    bias = torch.randn(N_, device=dev(), generator=g)
+    ref = (A.float() @ B.float().t()).double() if K > 1024 else A.double() @ B.double().t()
+    close_bf16(run_gemm(L, A, B, M, N_, K), ref, "plain")
+    close_bf16(run_gemm(L, A, B, M, N_, K, bias=bias, relu=1), torch.relu(ref + bias.double()), "bias+relu")
+    G = bf(torch.randn(M, N_, device=dev(), generator=g)); R = bf(torch.randn(M, N_, device=dev(), generator=g))
+    out = run_gemm(L, A, B, M, N_, K, gate=G, ldg=N_, gate_scale=1.25)
+    close_bf16(out, torch.where(G.double() > 0, ref * 1.25, torch.zeros_like(ref)), "gate")
+    del out
+    close_bf16(run_gemm(L, A, B, M, N_, K, bias=bias, residual=R, ldr=N_), ref + bias.double() + R.double(), "bias+residual")
+    dr = _drop(7, 11, 3, 0.1)
+    out = run_gemm(L, A, B, M, N_, K, bias=bias, drop=dr, residual=R, ldr=N_)
+    pre = ref + bias.double()
+    kept = out != R                                     # a dropped element is the residual, exactly
+    frac = kept.float().mean().item()
+    assert abs(frac - 0.9) < 0.01, frac
+    close_bf16(out.float()[kept], (pre / 0.9 + R.double()).float()[kept], "dropout+residual")
+    # same (seed, step, site, element) mask as the tiled kernel on a row range small enough to stay on it
+    Ms = 1500
+    out_s = run_gemm(L, A[:Ms], B, Ms, N_, K, bias=bias, drop=dr, residual=R[:Ms], ldr=N_)
+    sel = pre[:Ms].abs() > 0.05
+    assert torch.equal((out_s != R[:Ms])[sel], kept[:Ms][sel])
+
+
 @pytest.mark.parametrize("D,K", [(192, 192), (192, 768), (128, 128), (128, 1024), (256, 256), (256, 1024), (128, 64)])
 @pytest.mark.parametrize("M,pdrop", [(1000, 0.0), (50432, 0.1), (130, 0.25), (77, 0.0)])
 def test_gemm_with_fused_layernorm_tail_equals_gemm_then_layernorm(L, D, K, M, pdrop):

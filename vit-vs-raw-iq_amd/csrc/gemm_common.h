@@ -197,3 +197,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
   __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): every load above has landed; none below (PE variant excepted)
   epi_finish<MT, NT, EPI, LDSOUT>(p, acc, R, row0, col0, lane, hs, lrow0, lcol0);
 }
+
+// gemm_big.hip: 256 x 256 tiles, persistent, for the MFMA-bound shapes (N % 256 == 0, K >= 256, enough tiles to fill the
+// chip twice).  Launches and returns true when the shape and epilogue are its own.
+bool gemm_big_try(const GemmParams& p, int epi_mode, hipStream_t st);
