@@ -425,8 +425,8 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
     if (N > ZERO_BIAS_FLOATS || !zero_bias()) return IQ_ERR_UNSUPPORTED;
     p.bias = zero_bias();
   }
-  if (async_ok && gemm_big_try(p, epi_mode, st)) return iq_launch_status();
   p.stagger = 2;      // measured best of {0, 2, 6} (profiles/r01_probes.txt)
+  if (async_ok && gemm_big_try(p, epi_mode, st)) return iq_launch_status();
   // C = A W^T + R, nothing else in the tail, whole rows in one 192- / 128-column tile: residual streamed as extra K stages.
   // (the plain 192-column tile reads A once -- N=192 K=768: 27.6 vs 37.3 us -- but lost it all to an exposed residual fetch)
   if (async_ok && epi_mode == EPI_RES && (N == 192 || N == 128) && K >= 384 && !has_bias && !p.relu && !p.drop_on &&
