@@ -1,18 +1,29 @@
-// bf16 MFMA GEMM for the MFMA-bound shapes, C[M,N] = epilogue(A[M,K] * B[N,K]^T) with N % 256 == 0, K >= 256 (gfx950):
-// every Linear of ViT-Base (V/models/amc_transformer.py:9 at D768 / F3072; multi_head_attention.py:18,28,
+// bf16 MFMA GEMM for the MFMA-bound shapes, C[M,N] = epilogue(A[M,K] * B[N,K]^T) with N % 256 == 0, K % 64 == 0, K >= 256
+// (gfx950): every Linear of ViT-Base (V/models/amc_transformer.py:9 at D768 / F3072; multi_head_attention.py:18,28,
 // position_wise_feed_forward.py:13-16) and its data gradients.  The 128 x 128 tiles of gemm_nt.hip are built for
 // K = 192 (three independent workgroups per CU hide a 6-stage loop's fill and drain); at K = 768..3072 they reach 0.28 of
-// the MFMA peak, because a 128 x 128 x 32 stage is only 16 MFMAs per wave behind 8 LDS fragment reads and a barrier.
+// the MFMA peak.
 //
-//   tile 256 x 256, 8 waves as 2 (M) x 4 (N), 128 x 64 per wave = 8 x 4 accumulator tiles (128 VGPRs),
-//   32 MFMAs per wave per 32-deep stage behind 12 fragment reads (0.375 reads / MFMA, was 0.5),
-//   operands by global_load_lds into a 4-slot ring of [A 256 rows | B 256 rows] x 64 B stages (128 KiB: one workgroup per
-//   CU), three stages in flight across ONE raw s_barrier per stage, counted vmcnt (never 0 inside the loop),
-//   rows XOR-swizzled on the global side exactly as in gemm_nt.hip (conflict-free ds_read_b128),
-//   the shared register-only epilogue (gemm_common.h: bias, ReLU, dropout, gate, residual) over two row tiles at a time.
-// Persistent over tiles: a workgroup walks its share of the tile list and issues the next tile's first three stages
-// BEFORE the current tile's epilogue, so the ring never drains at a tile boundary and the epilogue's loads and stores
-// run under operand traffic -- with one workgroup per CU nothing else would hide them.
+// Structure (the 256 x 256 "quadrant" schedule of the CDNA4 playbook, cdna_hip_programming.md section 5, rebuilt here as a
+// persistent kernel with this library's epilogue):
+//   * tile 256 x 256, K-tile 64, 8 waves as 2 (M) x 4 (N), 128 x 64 per wave = 8 x 4 accumulator tiles (128 VGPRs);
+//   * operands arrive by global_load_lds in WHOLE 128-byte lines (8 rows x 128 B per wave-instruction: 42 B/clk/CU from
+//     L2 against 27 for the 16 rows x 64 B pieces of a 32-deep stage, scripts/dbg/dma_probe.hip -- a 256 x 256 tile needs
+//     32 B/clk/CU at the MFMA rate), rows XOR-swizzled on the global side (chunk ^ (row >> 1) & 7): conflict-free
+//     ds_read_b128 on 128-byte rows;
+//   * a K-tile is four 16 KiB units: A0 / A1 = every wave's first / second 64 rows, B0 / B1 = every wave's first / second
+//     32 columns; two sets of four (128 KiB, one workgroup per CU).  Two phases per K-tile: X = quadrants (A0,B0) (A0,B1)
+//     behind 16 fragment reads (A0, B0, B1), Y = (A1,B1) (A1,B0) behind 8 (A1; the B fragments stay in registers):
+//     24 reads per 64 MFMAs.  Two units are requested per phase, each two or three phases before its first read and
+//     as soon as the slot it overwrites has been read for the last time: X(g) requests B1 A1 of K-tile g+1, Y(g) requests
+//     A0 B0 of K-tile g+2 (the slots of A0 B0 of K-tile g, which X(g) moved to registers); counted vmcnt, never 0 in
+//     the loop; the loop carries no address arithmetic (uniform base + tile-invariant per-lane offsets, M % 256 == 0);
+//   * ping-pong: the four waves of row half 1 run one barrier behind those of row half 0 (every SIMD holds one wave of
+//     each half): between two barriers one half reads fragments and issues its DMA pieces while the other half issues
+//     MFMAs, then they swap -- LDS latency, DMA issue and barrier skew sit under the partner's MFMAs;
+//   * persistent over tiles: the unit stream crosses tile boundaries, so the next tile's first K-tile is in flight under
+//     the epilogue; the epilogue (gemm_common.h: bias, ReLU, dropout, gate, residual; register-only) issues all its loads,
+//     waits once and stores 16 x 16 B per lane back to back.
 #include "common.h"
 #include "gemm_common.h"
 #include "iqvit.h"
@@ -20,36 +31,28 @@
 
 namespace {
 
-#ifndef BG_NS_
-#define BG_NS_ 4
-#endif
-constexpr int BG_THREADS = 512, BG_BM = 256, BG_BN = 256, BG_BK = 32, BG_NS = BG_NS_, BG_DIST = BG_NS - 1;
-constexpr int BG_STAGE = (BG_BM + BG_BN) * BG_BK * 2;     // 32 KiB
-constexpr int BG_PS = BG_STAGE / 1024 / 8;                // DMA pieces (16 rows x 64 B) per wave per stage: 4
+constexpr int BG_THREADS = 512, BG_BM = 256, BG_BN = 256, BG_KT = 64, BG_UNIT = 128 * 128;   // unit: 128 rows x 128 B
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
-
-__device__ __forceinline__ int bswz64(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }   // {0,2,3,1}: gemm_nt.hip
 
 // s_waitcnt immediate that waits for vmcnt <= n only (gfx9 layout: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
 constexpr int bg_vmcnt(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
 
 template <int EPI>
 __global__ __launch_bounds__(BG_THREADS, 1) void gemm_big_kernel(const GemmParams p, int ntiles) {
-  constexpr int MT = 8, NT = 4, PS = BG_PS;
+  constexpr int MT = 8, NT = 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int nk = p.K / BG_BK;
-  const int prow = lane >> 2, pch = lane & 3, ch = lane >> 4;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nkt = p.K / BG_KT;
+  const int ch = lane >> 4, c16 = lane & 15;
 
   // Tile list: logical id -> (row block, column block), column fastest, so that the workgroups of one XCD (contiguous
   // logical ids after the remap) share A row blocks and sweep the whole weight through that XCD's L2.
   const int first = xcd_remap(blockIdx.x, gridDim.x);
-  // stage q of this workgroup's stream = tile (q / nk) of its list, k-slice (q % nk)
   const int my_tiles = (ntiles - first + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int nstage = my_tiles * nk;
+  const int total_kt = my_tiles * nkt;
   auto tile_rc = [&](int ti, int& m0, int& n0) {
     const int t = first + ti * (int)gridDim.x;
     m0 = (t / p.tiles_n) * BG_BM;
@@ -57,152 +60,193 @@ __global__ __launch_bounds__(BG_THREADS, 1) void gemm_big_kernel(const GemmParam
   };
   const IqRng rng = p.drop_on ? rng_resolve(p.rng) : p.rng;     // oldest entry of the vector-memory queue
 
-  // The issue stream runs three stages ahead of the compute stream and crosses tile boundaries: its own tile / k-slice /
-  // ring-slot state, row pointers recomputed once per tile (4 per wave: pieces 4w..4w+3; 0..15 are A rows, 16..31 B rows).
-  int iq = 0, iks = 0, iti = 0, islot = 0;
-  const bf16* isrc[PS];
-  auto issue_setup = [&]() {
+  // ---- the unit stream ------------------------------------------------------------------------------------------------------
+  // Request order per K-tile: A0 B0 | B1 A1 (the bar = a phase boundary).  LDS slot of a unit: set * 4 + {A0: 0, A1: 1,
+  // B0: 2, B1: 3}, set = K-tile parity.  A wave's two pieces of a unit are unit rows 16 w .. 16 w + 15; a lane's source =
+  // (uniform tile / K-tile base) + (tile-invariant per-lane offset): M % 256 == 0 and N % 256 == 0, nothing is clamped.
+  unsigned offA[2][2], offB[2][2];                               // [half][piece], bytes
+  // (recomputed behind every epilogue from an opaque copy of the lane id: kept live across the epilogue they are what the
+  //  register allocator spills -- and a scratch reload in the loop is a vmcnt entry that drains the DMA queue)
+  auto lane_offsets = [&]() {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ur = (wave * 2 + i) * 8 + (l >> 3);              // row inside the unit
+      const int gch = ((l & 7) ^ ((ur >> 1) & 7)) * 16;          // source chunk of this lane's LDS position, bytes
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        offA[half][i] = (unsigned)(((ur >> 6) * 128 + half * 64 + (ur & 63)) * p.lda * 2 + gch);
+        offB[half][i] = (unsigned)(((ur >> 5) * 64 + half * 32 + (ur & 31)) * p.ldb * 2 + gch);
+      }
+    }
+  };
+  lane_offsets();
+  int iti = 0, ikt = 0, iset = 0;                                // the K-tile whose units are being requested
+  const char *ibaseA, *ibaseB;
+  auto issue_base = [&]() {
     int m0, n0;
     tile_rc(iti, m0, n0);
+    ibaseA = reinterpret_cast<const char*>(p.A + (long)m0 * p.lda);
+    ibaseB = reinterpret_cast<const char*>(p.B + (long)n0 * p.ldb);
+  };
+  auto issue_a = [&](int half) {
 #pragma unroll
-    for (int i = 0; i < PS; ++i) {
-      const int piece = wave * PS + i;
-      const int row = (piece & 15) * 16 + prow;
-      isrc[i] = (piece < 16 ? p.A + (long)min(m0 + row, p.M - 1) * p.lda : p.B + (long)min(n0 + row, p.N - 1) * p.ldb) +
-                (pch ^ bswz64(row)) * 8;
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(ibaseA + ikt * (BG_KT * 2) + offA[half][i]),
+                                       (lds_void_t*)(smem + (iset * 4 + half) * BG_UNIT + (wave * 2 + i) * 1024), 16, 0, 0);
+  };
+  auto issue_b = [&](int half) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(ibaseB + ikt * (BG_KT * 2) + offB[half][i]),
+                                       (lds_void_t*)(smem + (iset * 4 + 2 + half) * BG_UNIT + (wave * 2 + i) * 1024), 16, 0, 0);
+  };
+  auto issue_advance = [&]() {                                   // after B1, A1: the next K-tile, other set
+    iset ^= 1;
+    if (++ikt == nkt) {
+      ikt = 0;
+      if (++iti < my_tiles) issue_base();
     }
   };
-  auto issue_piece = [&](int i) {
-#ifdef BG_NO_DMA    // ablation build: timing only
-    return;
-#endif
-    __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(isrc[i] + iks * BG_BK),
-                                     (lds_void_t*)(smem + islot * BG_STAGE + (wave * PS + i) * 1024), 16, 0, 0);
-  };
-  auto issue_advance = [&]() {
-    ++iq;
-    islot = islot + 1 == BG_NS ? 0 : islot + 1;
-    if (++iks == nk) {
-      iks = 0;
-      if (++iti < my_tiles) issue_setup();
-    }
-  };
-  issue_setup();
-#pragma unroll
-  for (int s = 0; s < BG_DIST; ++s) {                            // (nstage >= nk >= 8)
-#pragma unroll
-    for (int i = 0; i < PS; ++i) issue_piece(i);
-    issue_advance();
-  }
+  // prologue: K-tile 0 whole, A0 B0 of K-tile 1 (total_kt >= nkt >= 4)
+  issue_base();
+  issue_a(0); issue_b(0); issue_b(1); issue_a(1);
+  issue_advance();
+  issue_a(0); issue_b(0);
 
-  // Ping-pong: the four waves of row half 1 run one barrier behind those of row half 0 (a workgroup's waves go to SIMDs
-  // round-robin, so every SIMD holds one wave of each half).  Between two barriers one half reads its 12 fragments while
-  // the other half runs its 32 MFMAs with its 4 DMA pieces of stage q+3 issued between them (a piece costs ~60 cycles
-  // of issue among bare MFMAs, 100-185 in a phase that also carries the fragment reads), then they swap: LDS latency
-  // and barrier skew hide under the partner's MFMAs.  Two barriers per stage, all eight waves at each.
-  //   barrier 2q   .. 2q+1 : half 0 reads stage q                  | half 1 MFMAs stage q-1, issues q+2
-  //   barrier 2q+1 .. 2q+2 : half 0 MFMAs stage q, issues q+3      | half 1 reads stage q
-  // Stage q+1 is waited for (counted vmcnt) by every wave before barrier 2q+2: half 0 after its MFMAs, half 1 after its
-  // reads.  A ring slot is refilled (stage q+3 over stage q-1) only after barrier 2q+1, behind which both halves' reads
-  // of stage q-1 have returned (lgkmcnt(0) sits before the barrier that ends a read phase).
-  __builtin_amdgcn_s_waitcnt(bg_vmcnt((BG_DIST - 1) * PS));
-  __builtin_amdgcn_s_barrier();                                  // barrier 0: stage 0 is visible
-  if (wm == 1) __builtin_amdgcn_s_barrier();                     // half 1: one phase behind
+  __builtin_amdgcn_s_waitcnt(bg_vmcnt(6));                       // A0, B0, B1 of K-tile 0 landed (A1, A0', B0' in flight)
+  __builtin_amdgcn_s_barrier();                                  // barrier 0
+  if (wr == 1) __builtin_amdgcn_s_barrier();                     // half 1 runs one phase-half behind
 
   f32x4 acc[MT][NT];
-  int q = 0, cslot = 0;
-  auto epilogue = [&](int ti) {
-    // every load of the tail first (the fragment registers are dead here: the 64 residual / gate registers fit), one
-    // wait -- which also retires the next tile's first stages -- then 16 stores back to back
-    int m0, n0;
-    tile_rc(ti, m0, n0);
-    const int row0 = m0 + wm * 128, col0 = n0 + wn * 64;
-    EpiRegs<MT, NT, EPI> R;
-    R.rng = rng;
-    epi_load_early<MT, NT, EPI>(p, R, row0, col0, lane);
-    __builtin_amdgcn_s_waitcnt(bg_vmcnt(0));
-    epi_finish<MT, NT, EPI>(p, acc, R, row0, col0, lane);
+  bf16x8 af[8], bfr[8];          // A fragments [row tile rt][k-step h] of one A unit; B fragments [half j][col tile ct][h]
+  int cset = 0;
+  auto read_a = [&](int half) {
+    const unsigned char* U = smem + (cset * 4 + half) * BG_UNIT;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int ur = wr * 64 + rt * 16 + c16;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) af[rt * 2 + h] = *reinterpret_cast<const bf16x8*>(U + ur * 128 + (((h * 4 + ch) ^ ((ur >> 1) & 7)) << 4));
+    }
   };
-  // Stage q+1 must have landed before the barrier that follows.  Entries of this wave's queue younger than its pieces:
-  // those of the stages issued after it (iq - q - 2 of them).  fresh = the first two stages behind a tile boundary:
-  // stage q+1 was issued before the epilogue, whose vmcnt(0) retired it, and a wait here would wait for its stores.
-  auto wait_next = [&](bool fresh) {
-#ifdef BG_NO_WAIT   // ablation build: timing only
-    return;
-#endif
-    if (fresh || q + 1 >= nstage) return;
-    const int y = iq - q - 2;
-    if (y >= 3) __builtin_amdgcn_s_waitcnt(bg_vmcnt(3 * PS));
-    else if (y == 2) __builtin_amdgcn_s_waitcnt(bg_vmcnt(2 * PS));
-    else if (y == 1) __builtin_amdgcn_s_waitcnt(bg_vmcnt(PS));
-    else __builtin_amdgcn_s_waitcnt(bg_vmcnt(0));
+  auto read_b = [&](int half) {
+    const unsigned char* U = smem + (cset * 4 + 2 + half) * BG_UNIT;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int ur = wc * 32 + ct * 16 + c16;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        bfr[half * 4 + ct * 2 + h] = *reinterpret_cast<const bf16x8*>(U + ur * 128 + (((h * 4 + ch) ^ ((ur >> 1) & 7)) << 4));
+    }
   };
+  // The two halves of a phase: [fragment reads, two units requested, reads returned | barrier | 32 MFMAs | barrier].  What
+  // the NEXT phase reads must have landed before the second barrier: half 1 waits for it in its read part, half 0 after
+  // its MFMAs (both sit before the same barrier).  `left` = entries of this wave's queue that may stay outstanding.
+  auto sync_a = [&](int left) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (wr == 1) {
+      if (left == 8) __builtin_amdgcn_s_waitcnt(bg_vmcnt(8));
+      else if (left == 6) __builtin_amdgcn_s_waitcnt(bg_vmcnt(6));
+      else if (left == 2) __builtin_amdgcn_s_waitcnt(bg_vmcnt(2));
+      else if (left == 0) __builtin_amdgcn_s_waitcnt(bg_vmcnt(0));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto sync_b = [&](int left) {
+    if (wr == 0) {
+      if (left == 8) __builtin_amdgcn_s_waitcnt(bg_vmcnt(8));
+      else if (left == 6) __builtin_amdgcn_s_waitcnt(bg_vmcnt(6));
+      else if (left == 2) __builtin_amdgcn_s_waitcnt(bg_vmcnt(2));
+      else if (left == 0) __builtin_amdgcn_s_waitcnt(bg_vmcnt(0));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#define BG_MFMA(AI, BJ)                                                                                                       \
+  do {                                                                                                                        \
+    _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                          \
+      _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                                                        \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                                         \
+          acc[(AI) * 4 + rt][(BJ) * 2 + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                        \
+              bfr[(BJ) * 4 + ct * 2 + h], af[rt * 2 + h], acc[(AI) * 4 + rt][(BJ) * 2 + ct], 0, 0, 0);                        \
+  } while (0)
+
+  int g = 0;                     // K-tiles done (this workgroup's stream)
   for (int ti = 0; ti < my_tiles; ++ti) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int ks = 0; ks < nk; ++ks, ++q) {
-      const bool fresh = ti > 0 && ks < BG_DIST - 1;
-      // ---- read phase ----------------------------------------------------------------------------------------------
-      const bf16* As = reinterpret_cast<const bf16*>(smem + cslot * BG_STAGE);
-      cslot = cslot + 1 == BG_NS ? 0 : cslot + 1;
-      const bf16* Bs = As + BG_BM * BG_BK;
-      bf16x8 af[MT], bfr[NT];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int row = wn * 64 + j * 16 + (lane & 15);
-        bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + row * BG_BK + (ch ^ bswz64(row)) * 8);
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int row = wm * 128 + i * 16 + (lane & 15);
-        af[i] = *reinterpret_cast<const bf16x8*>(As + row * BG_BK + (ch ^ bswz64(row)) * 8);
-      }
-      if (iq < nstage) {                                          // wave-uniform: stage q+3, into the slot of stage q-1
-#pragma unroll
-        for (int i = 0; i < PS; ++i) issue_piece(i);
-        issue_advance();
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (wm == 1) wait_next(fresh);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- MFMA phase ----------------------------------------------------------------------------------------------
+    for (int kt = 0; kt < nkt; ++kt, ++g) {
+      // Queue of this wave at the two wait points of K-tile g (2 entries per unit), oldest first:
+      //   end of X(g): A1[g] | A0 B0 B1 A1 of g+1   -> A1[g] landed <=> at most 8 left (fewer near the end of the stream)
+      //   end of Y(g): B1 A1 of g+1 | A0 B0 of g+2  -> B1[g+1] landed <=> at most 6 left
+      // Behind an epilogue (vmcnt(0): everything requested before it has landed) the first X of a tile does not wait: a
+      // counted wait there would wait for the epilogue's stores.
+      const bool fresh = ti > 0 && kt == 0;
+      // phase X: quadrants (A0, B0), (A0, B1); requests B1, A1 of K-tile g+1
+      read_b(0);
+      read_b(1);
+      read_a(0);
+      const bool more1 = g + 1 < total_kt;
+      if (more1) { issue_b(1); issue_a(1); issue_advance(); }
+      sync_a(fresh ? -1 : more1 ? 8 : 0);
       __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile: gemm_common.h
+      BG_MFMA(0, 0);
+      BG_MFMA(0, 1);
       __builtin_amdgcn_s_setprio(0);
-      if (wm == 0) wait_next(fresh);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
+      sync_b(fresh ? -1 : more1 ? 8 : 0);
+      // phase Y: (A1, B1), (A1, B0); requests A0, B0 of K-tile g+2
+      read_a(1);
+      const bool more2 = g + 2 < total_kt;
+      if (more2) { issue_a(0); issue_b(0); }
+      sync_a(more2 ? 6 : more1 ? 2 : -1);
+      __builtin_amdgcn_s_setprio(1);
+      BG_MFMA(1, 1);
+      BG_MFMA(1, 0);
+      __builtin_amdgcn_s_setprio(0);
+      sync_b(more2 ? 6 : more1 ? 2 : -1);
+      cset ^= 1;
     }
-    // In program order the epilogue follows the tile's last barrier: it runs in the partner half's MFMA phase of that
-    // stage (half 0) or of the next tile's first stage (half 1), with the next tile's first three stages in flight.
-    epilogue(ti);
+    // Epilogue, in program order behind the tile's last barrier: it runs in the partner half's MFMA phase (half 0) or
+    // under the partner's first phase of the next tile (half 1).  Every load of the tail first (the fragment registers
+    // are dead here), one wait -- which also retires the units already requested for the next tile -- then 16 stores.
+    {
+      int m0, n0;
+      tile_rc(ti, m0, n0);
+      const int row0 = m0 + wr * 128, col0 = n0 + wc * 64;
+      EpiRegs<MT, NT, EPI> R;
+      R.rng = rng;
+      epi_load_early<MT, NT, EPI>(p, R, row0, col0, lane);
+      __builtin_amdgcn_s_waitcnt(bg_vmcnt(0));
+      epi_finish<MT, NT, EPI>(p, acc, R, row0, col0, lane);
+    }
+    lane_offsets();
   }
-  if (wm == 0) __builtin_amdgcn_s_barrier();                     // matches half 1's extra barrier at the start
+#undef BG_MFMA
+  if (wr == 0) __builtin_amdgcn_s_barrier();                     // matches half 1's extra barrier at the start
 }
 
 }  // namespace
 
-// Called by iq_gemm_bf16_nt with its resolved parameters.  Returns false when the shape / epilogue is not this kernel's.
+// Called by iq_gemm_bf16_nt with its resolved parameters (bias non-null).  Returns false when the shape / epilogue is not
+// this kernel's; true after a launch.
 bool gemm_big_try(const GemmParams& p0, int epi_mode, hipStream_t st) {
   if (epi_mode != 0 && epi_mode != EPI_RES && epi_mode != EPI_GATE) return false;
-  if (p0.N % BG_BN != 0 || p0.K % BG_BK != 0 || p0.K < 256 || p0.M < 2048) return false;
+  if (p0.N % BG_BN != 0 || p0.K % BG_KT != 0 || p0.K < 256 || p0.M % BG_BM != 0) return false;
   if ((((uintptr_t)p0.A | (uintptr_t)p0.B | (uintptr_t)p0.C) % 16) || (p0.ldc % 8)) return false;
   GemmParams p = p0;
   p.tiles_m = (p.M + BG_BM - 1) / BG_BM;
   p.tiles_n = p.N / BG_BN;
   const int ntiles = p.tiles_m * p.tiles_n;
   if (ntiles < 512) return false;                          // fewer than two rounds of 256 CUs: the 128 x 128 tiles fill the chip better
-  const int grid = ntiles < 256 ? ntiles : 256;            // one workgroup per CU, persistent over its share of the tiles
-  const size_t lds = (size_t)BG_NS * BG_STAGE;             // 128 KiB
+  const int grid = 256;                                    // one workgroup per CU, persistent over its share of the tiles
+  const size_t lds = (size_t)8 * BG_UNIT;                  // 128 KiB
 #define IQ_BIG_LAUNCH(E)                                                                                              \
   do {                                                                                                                \
     auto k = gemm_big_kernel<E>;                                                                                      \
