@@ -45,6 +45,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "big":        # ViT-Base shapes (M = 512
     for (n_, k_, kw) in ((2304, 768, dict(bias=True)), (768, 768, dict(bias=True, drop=0.1, res=True)), (3072, 768, dict(bias=True, relu=True, drop=0.1)),
                          (768, 3072, dict(bias=True, drop=0.1, res=True)), (3072, 768, dict(gate=True)), (768, 3072, dict(res=True)), (768, 2304, dict(res=True)), (768, 768, dict())):
         nt(n_, k_, **kw)
+    wg(768, 768); wg(2304, 768); wg(3072, 768); wg(768, 3072)
     sys.exit(0)
 if len(sys.argv) > 2:
     nt = wg = lambda *a, **k: None

@@ -479,7 +479,9 @@ def test_dropout_statistics_and_regeneration(L):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N_,K", [(64, 128, 128), (1000, 192, 192), (5000, 768, 192), (3333, 192, 768),
                                     (777, 576, 192), (130, 40, 72), (4096, 128, 32), (20000, 128, 1024),
-                                    (31, 64, 64), (700, 1024, 768)])   # last: N*K > 512 Ki -> shared-tile kernel
+                                    (31, 64, 64), (700, 1024, 768),    # N*K > 512 Ki, few rows -> shared-tile kernel
+                                    (8192, 768, 768), (16384, 1024, 768), (4096 + 64, 768, 2304), (100864, 768, 768),
+                                    (12800, 3072, 768)])               # whole 64-row steps, 256-multiples: gemm_wgrad_big.hip
 def test_wgrad(L, M, N_, K):
     N = _N()
     g = torch.Generator(device="cuda").manual_seed(M + 3 * N_ + K)

@@ -19,6 +19,12 @@
 #include "iqvit.h"
 #include "prof.h"
 
+// gemm_wgrad_big.hip: 256 x 256 output tiles for the MFMA-bound shapes (ViT-Base)
+bool wgrad_big_eligible(int M, int N, int K);
+size_t wgrad_big_ws_floats(int M, int N, int K);
+void wgrad_big_launch(const void* dY, int ldy, const void* X, int ldx, int M, int N, int K, float* ws, bool with_bias, int* splits,
+                      float** bslab, hipStream_t st);
+
 namespace {
 
 constexpr int WG_THREADS = 512;   // 8 waves: 2 (n) x 4 (k); two workgroups per CU hide the HBM latency of the single-stage loop
@@ -509,7 +515,10 @@ inline bool group_is_pw(const iq_wgrad_problem_t* pr, int nprob) {
 }
 inline size_t shared_ws_floats(int M, int N, int K) {
   const WgradPlan w = wgrad_plan(M, N, K);
-  return (size_t)w.splits * (pad4((size_t)N * K) + pad4(N));
+  const size_t f = (size_t)w.splits * (pad4((size_t)N * K) + pad4(N));
+  if (!wgrad_big_eligible(M, N, K)) return f;
+  const size_t fb = wgrad_big_ws_floats(M, N, K);           // (operand alignment may still send the call to the shared-tile kernel)
+  return fb > f ? fb : f;
 }
 
 #ifdef IQ_WGRAD_STAMPS
@@ -523,6 +532,20 @@ int launch_reduce(const RedGroup& rg, int nblk, hipStream_t st) {
 
 int wgrad_shared_one(const iq_wgrad_problem_t& pb, int M, float* ws, int accumulate, hipStream_t st) {
   const int N = pb.N, K = pb.K;
+  if (wgrad_big_eligible(M, N, K) && (pb.ldy % 64) == 0 && (pb.ldx % 64) == 0 && (((uintptr_t)pb.dY | (uintptr_t)pb.X) % 128) == 0) {
+    int splits = 0;
+    float* bslab = nullptr;
+    wgrad_big_launch(pb.dY, pb.ldy, pb.X, pb.ldx, M, N, K, ws, pb.dbias != nullptr, &splits, &bslab, st);
+    RedGroup rg;
+    memset(&rg, 0, sizeof(rg));
+    const long n = (long)N * K;
+    rg.s[0] = RedSeg{ws, pb.dW, n, n, splits, 0, 0};
+    int nblk = (int)((n + 255) / 256);
+    rg.nseg = 1;
+    if (pb.dbias) { rg.s[1] = RedSeg{bslab, pb.dbias, (long)N, (long)N, splits, nblk, 0}; nblk += (N + 255) / 256; rg.nseg = 2; }
+    rg.accumulate = accumulate;
+    return launch_reduce(rg, nblk, st);
+  }
   const WgradPlan w = wgrad_plan(M, N, K);
   WgradParams q;
   q.Y = (const bf16*)pb.dY; q.X = (const bf16*)pb.X; q.ldy = pb.ldy; q.ldx = pb.ldx; q.M = M; q.N = N; q.K = K;
