@@ -335,8 +335,8 @@ FULL = {
     "Cp": ("rawiq", dict(in_channels=2, seq_length=1024, num_classes=19, d_model=256, n_head=8, n_layers=9,
                          ffn_hidden=1024, use_cls_token=True, embedding_type="segment", segment_size=16), 128),
     "D_L2": ("vit", dict(in_channels=1, img_size_h=224, img_size_w=224, patch_size=16, num_classes=19, d_model=768,
-                         n_head=12, n_layers=2, ffn_hidden=3072), 128),
-}
+                         n_head=12, n_layers=2, ffn_hidden=3072), 256),   # 256 x 197 rows = 197 whole 256-row blocks: the full
+}                                                                         # batch runs gemm_big / wgrad_big, its halves the tiled kernels
 
 
 @pytest.mark.parametrize("cid", sorted(FULL))
