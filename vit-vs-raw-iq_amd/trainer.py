@@ -249,7 +249,9 @@ class FusedTrainer:
                 graphs = []
                 for seg in self._segments(self._static[0], self._static[1], auto_step=True):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    # thread_local: with a process group alive, its watchdog thread queries events while we capture;
+                    # in the default (global) mode that invalidates the capture.  Only this thread's stream is captured.
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         seg()
                     graphs.append(g)
                 self._graphs = graphs
