@@ -181,11 +181,11 @@ def test_gemm_wide_n_many_rows(L, M, N_, K):
 
 
 @pytest.mark.parametrize("M,N_,K", [(50432, 768, 768), (40192, 1024, 256), (40000 + 77, 1024, 256), (100864, 768, 3072), (35072, 2304, 768),
-                                    (65536, 512, 320)])
+                                    (65536, 512, 320), (50000, 768, 768)])
 def test_gemm_big_tiles(L, M, N_, K):
     """The MFMA-bound shapes (ViT-Base: D 768, F 3072, 512 frames x 197 tokens) run the persistent 256 x 256-tile kernel
-    (gemm_big.hip; whole 256-row blocks only -- 40077 rows stay on the tiled kernel): every epilogue it serves, 4 to 48
-    K-tiles, an odd K-tile count (K = 320), and the same dropout mask as the tiled kernel."""
+    (gemm_big.hip): every epilogue it serves, 4 to 48 K-tiles, an odd K-tile count (K = 320), ragged last row blocks
+    (40077 and 50000 rows), and the same dropout mask as the tiled kernel."""
     g = torch.Generator(device="cuda").manual_seed(M + N_ + K)
     A = bf(torch.randn(M, K, device=dev(), generator=g))
     B = bf(torch.randn(N_, K, device=dev(), generator=g) / math.sqrt(K))

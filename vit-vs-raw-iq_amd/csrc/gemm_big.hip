@@ -17,7 +17,7 @@
 //     24 reads per 64 MFMAs.  Two units are requested per phase, each two or three phases before its first read and
 //     as soon as the slot it overwrites has been read for the last time: X(g) requests B1 A1 of K-tile g+1, Y(g) requests
 //     A0 B0 of K-tile g+2 (the slots of A0 B0 of K-tile g, which X(g) moved to registers); counted vmcnt, never 0 in
-//     the loop; the loop carries no address arithmetic (uniform base + tile-invariant per-lane offsets, M % 256 == 0);
+//     the loop; the loop carries no address arithmetic (uniform base + per-lane offsets that change only at a ragged row block);
 //   * ping-pong: the four waves of row half 1 run one barrier behind those of row half 0 (every SIMD holds one wave of
 //     each half): between two barriers one half reads fragments and issues its DMA pieces while the other half issues
 //     MFMAs, then they swap -- LDS latency, DMA issue and barrier skew sit under the partner's MFMAs;
@@ -63,8 +63,10 @@ __global__ __launch_bounds__(BG_THREADS, 1) void gemm_big_kernel(const GemmParam
   // ---- the unit stream ------------------------------------------------------------------------------------------------------
   // Request order per K-tile: A0 B0 | B1 A1 (the bar = a phase boundary).  LDS slot of a unit: set * 4 + {A0: 0, A1: 1,
   // B0: 2, B1: 3}, set = K-tile parity.  A wave's two pieces of a unit are unit rows 16 w .. 16 w + 15; a lane's source =
-  // (uniform tile / K-tile base) + (tile-invariant per-lane offset): M % 256 == 0 and N % 256 == 0, nothing is clamped.
+  // (uniform tile / K-tile base) + (per-lane offset that only changes with the tile's row count: the rows of a ragged
+  // last row block are clamped to its last valid row, their outputs are never stored).
   unsigned offA[2][2], offB[2][2];                               // [half][piece], bytes
+  int irows = BG_BM;                                             // valid rows of the tile being requested
   // (recomputed behind every epilogue from an opaque copy of the lane id: kept live across the epilogue they are what the
   //  register allocator spills -- and a scratch reload in the loop is a vmcnt entry that drains the DMA queue)
   auto lane_offsets = [&]() {
@@ -76,12 +78,11 @@ __global__ __launch_bounds__(BG_THREADS, 1) void gemm_big_kernel(const GemmParam
       const int gch = ((l & 7) ^ ((ur >> 1) & 7)) * 16;          // source chunk of this lane's LDS position, bytes
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        offA[half][i] = (unsigned)(((ur >> 6) * 128 + half * 64 + (ur & 63)) * p.lda * 2 + gch);
+        offA[half][i] = (unsigned)(min((ur >> 6) * 128 + half * 64 + (ur & 63), irows - 1) * p.lda * 2 + gch);
         offB[half][i] = (unsigned)(((ur >> 5) * 64 + half * 32 + (ur & 31)) * p.ldb * 2 + gch);
       }
     }
   };
-  lane_offsets();
   int iti = 0, ikt = 0, iset = 0;                                // the K-tile whose units are being requested
   const char *ibaseA, *ibaseB;
   auto issue_base = [&]() {
@@ -89,7 +90,13 @@ __global__ __launch_bounds__(BG_THREADS, 1) void gemm_big_kernel(const GemmParam
     tile_rc(iti, m0, n0);
     ibaseA = reinterpret_cast<const char*>(p.A + (long)m0 * p.lda);
     ibaseB = reinterpret_cast<const char*>(p.B + (long)n0 * p.ldb);
+    const int rows = min(BG_BM, p.M - m0);
+    if (rows != irows) {                                         // uniform; entering or leaving the ragged row block
+      irows = rows;
+      lane_offsets();
+    }
   };
+  lane_offsets();
   auto issue_a = [&](int half) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(BG_THREADS, 1) void gemm_big_kernel(const GemmParam
 // this kernel's; true after a launch.
 bool gemm_big_try(const GemmParams& p0, int epi_mode, hipStream_t st) {
   if (epi_mode != 0 && epi_mode != EPI_RES && epi_mode != EPI_GATE) return false;
-  if (p0.N % BG_BN != 0 || p0.K % BG_KT != 0 || p0.K < 256 || p0.M % BG_BM != 0) return false;
+  if (p0.N % BG_BN != 0 || p0.K % BG_KT != 0 || p0.K < 256 || p0.M < 2048) return false;
   if ((((uintptr_t)p0.A | (uintptr_t)p0.B | (uintptr_t)p0.C) % 16) || (p0.ldc % 8)) return false;
   GemmParams p = p0;
   p.tiles_m = (p.M + BG_BM - 1) / BG_BM;
