@@ -506,6 +506,10 @@ def test_wgrad(L, M, N_, K):
     (3940, [(192, 768), (768, 192), (192, 192), (576, 192)], 256), # same with a workgroup budget (overlapped backward)
     (1000, [(128, 256), (40, 72)], 0),                             # partial tiles, two problems
     (515, [(64, 64), (1024, 768), (72, 64)], 0),                   # a large member: falls back to one launch per problem
+    (50432, [(192, 768), (768, 192), (192, 192), (576, 192)], 0),  # cfg B's layer at its batch: 256 x 192 LDS-shared tiles (gemm_wgrad_big.hip)
+    (16640, [(128, 1024), (1024, 128), (128, 128), (384, 128)], 0),  # cfg C's layer: column tile 128
+    (8192, [(768, 3072), (3072, 768), (768, 768), (2304, 768)], 0),  # ViT-Base's layer: column tile 256, one launch for all four
+    (4096, [(256, 512), (512, 256)], 0),
 ])
 def test_wgrad_grouped(L, M, shapes, budget):
     """Several weight gradients sharing M in one launch == each one alone (fp64 reference), with and without accumulate."""
@@ -513,13 +517,14 @@ def test_wgrad_grouped(L, M, shapes, budget):
     g = torch.Generator(device="cuda").manual_seed(M)
     probs = (N.WgradProblem * len(shapes))()
     keep, refs = [], []
+    pad = 64 if (M % 64 == 0 and M >= 4096) else 8      # (line-aligned rows keep the LDS-shared kernel eligible)
     for i, (n, k) in enumerate(shapes):
-        dY = bf(torch.randn(M, n + 8, device=dev(), generator=g))[:, :n]      # ld > N: strided operand
+        dY = bf(torch.randn(M, n + pad, device=dev(), generator=g))[:, :n]    # ld > N: strided operand
         X = bf(torch.randn(M, k, device=dev(), generator=g))
         dW = torch.full((n, k), 3.0, device=dev())
         db = torch.full((n,), 3.0, device=dev()) if i != 1 else None          # one problem without bias
         keep.append((dY, X, dW, db))
-        probs[i].dY = dY.data_ptr(); probs[i].ldy = n + 8; probs[i].X = X.data_ptr(); probs[i].ldx = k
+        probs[i].dY = dY.data_ptr(); probs[i].ldy = n + pad; probs[i].X = X.data_ptr(); probs[i].ldx = k
         probs[i].dW = dW.data_ptr(); probs[i].dbias = db.data_ptr() if db is not None else None
         probs[i].N = n; probs[i].K = k
         refs.append((dY.double().t() @ X.double(), dY.double().sum(0)))

@@ -19,11 +19,7 @@
 #include "iqvit.h"
 #include "prof.h"
 
-// gemm_wgrad_big.hip: 256 x 256 output tiles for the MFMA-bound shapes (ViT-Base)
-bool wgrad_big_eligible(int M, int N, int K);
-size_t wgrad_big_ws_floats(int M, int N, int K);
-void wgrad_big_launch(const void* dY, int ldy, const void* X, int ldx, int M, int N, int K, float* ws, bool with_bias, int* splits,
-                      float** bslab, hipStream_t st);
+#include "gemm_wgrad_big.h"
 
 namespace {
 
@@ -515,10 +511,7 @@ inline bool group_is_pw(const iq_wgrad_problem_t* pr, int nprob) {
 }
 inline size_t shared_ws_floats(int M, int N, int K) {
   const WgradPlan w = wgrad_plan(M, N, K);
-  const size_t f = (size_t)w.splits * (pad4((size_t)N * K) + pad4(N));
-  if (!wgrad_big_eligible(M, N, K)) return f;
-  const size_t fb = wgrad_big_ws_floats(M, N, K);           // (operand alignment may still send the call to the shared-tile kernel)
-  return fb > f ? fb : f;
+  return (size_t)w.splits * (pad4((size_t)N * K) + pad4(N));
 }
 
 #ifdef IQ_WGRAD_STAMPS
@@ -532,20 +525,6 @@ int launch_reduce(const RedGroup& rg, int nblk, hipStream_t st) {
 
 int wgrad_shared_one(const iq_wgrad_problem_t& pb, int M, float* ws, int accumulate, hipStream_t st) {
   const int N = pb.N, K = pb.K;
-  if (wgrad_big_eligible(M, N, K) && (pb.ldy % 64) == 0 && (pb.ldx % 64) == 0 && (((uintptr_t)pb.dY | (uintptr_t)pb.X) % 128) == 0) {
-    int splits = 0;
-    float* bslab = nullptr;
-    wgrad_big_launch(pb.dY, pb.ldy, pb.X, pb.ldx, M, N, K, ws, pb.dbias != nullptr, &splits, &bslab, st);
-    RedGroup rg;
-    memset(&rg, 0, sizeof(rg));
-    const long n = (long)N * K;
-    rg.s[0] = RedSeg{ws, pb.dW, n, n, splits, 0, 0};
-    int nblk = (int)((n + 255) / 256);
-    rg.nseg = 1;
-    if (pb.dbias) { rg.s[1] = RedSeg{bslab, pb.dbias, (long)N, (long)N, splits, nblk, 0}; nblk += (N + 255) / 256; rg.nseg = 2; }
-    rg.accumulate = accumulate;
-    return launch_reduce(rg, nblk, st);
-  }
   const WgradPlan w = wgrad_plan(M, N, K);
   WgradParams q;
   q.Y = (const bf16*)pb.dY; q.X = (const bf16*)pb.X; q.ldy = pb.ldy; q.ldx = pb.ldx; q.M = M; q.N = N; q.K = K;
@@ -585,8 +564,19 @@ extern "C" void iq_debug_set_wgrad_stamps(unsigned long long* p) { g_wstamps = p
 
 extern "C" size_t iq_wgrad_grouped_ws_bytes(const iq_wgrad_problem_t* probs, int nprob, int M, int max_workgroups) {
   if (!probs || nprob <= 0 || M <= 0) return 0;
-  if (group_is_pw(probs, nprob)) return pw_plan(probs, nprob, M, max_workgroups).floats * sizeof(float);
-  size_t mx = 0;                                    // run one at a time, sharing the area
+  // (sized for every kernel the call may choose: the choice also depends on operand alignment, unknown here)
+  WbPlan wb;
+  iq_wgrad_problem_t al[PW_MAXP];
+  size_t big = 0;
+  if (nprob <= PW_MAXP) {
+    for (int i = 0; i < nprob; ++i) { al[i] = probs[i]; al[i].dY = nullptr; al[i].X = nullptr; al[i].ldy = 64; al[i].ldx = 64; }
+    if (wgrad_big_plan(al, nprob, M, &wb)) big = wb.floats * sizeof(float);
+  }
+  if (group_is_pw(probs, nprob)) {
+    const size_t b = pw_plan(probs, nprob, M, max_workgroups).floats * sizeof(float);
+    return b > big ? b : big;
+  }
+  size_t mx = big / sizeof(float);                  // run one at a time, sharing the area
   for (int i = 0; i < nprob; ++i) {
     const size_t b = pw_eligible(probs[i].N, probs[i].K) ? pw_plan(probs + i, 1, M, max_workgroups).floats
                                                           : shared_ws_floats(M, probs[i].N, probs[i].K);
@@ -621,6 +611,28 @@ extern "C" int iq_gemm_bf16_wgrad_grouped(const iq_wgrad_problem_t* probs, int n
   if (ws_bytes < iq_wgrad_grouped_ws_bytes(probs, nprob, M, max_workgroups)) return IQ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   IQ_PROF(IQ_FAM_WGRAD, st);
+  WbPlan wb;
+  if (nprob > 0 && max_workgroups == 0 && wgrad_big_plan(probs, nprob, M, &wb) && ws_bytes >= wb.floats * sizeof(float)) {
+    // LDS-shared 256-row tiles (gemm_wgrad_big.hip): whole 64-row steps, line-aligned operands, one common column tile
+    float *slab[PW_MAXP], *bslab[PW_MAXP];
+    wgrad_big_launch(probs, nprob, M, wb, ws, slab, bslab, st);
+    RedGroup rg;
+    memset(&rg, 0, sizeof(rg));
+    int nblk = 0;
+    for (int i = 0; i < nprob; ++i) {
+      const long n = (long)probs[i].N * probs[i].K;
+      rg.s[rg.nseg++] = RedSeg{slab[i], probs[i].dW, n, (long)pad4((size_t)n), wb.splits, nblk, 0};
+      nblk += (int)((n + 255) / 256);
+      if (probs[i].dbias) {
+        rg.s[rg.nseg++] = RedSeg{bslab[i], probs[i].dbias, (long)probs[i].N, (long)pad4(probs[i].N), wb.splits, nblk, 0};
+        nblk += (probs[i].N + 255) / 256;
+      }
+    }
+    add_extra(rg, nblk);
+    rg.accumulate = accumulate;
+    launch_reduce(rg, nblk, st);
+    return iq_launch_status();
+  }
   if (!group_is_pw(probs, nprob)) {
     for (int i = 0; i < nprob; ++i) {
       int rc;
