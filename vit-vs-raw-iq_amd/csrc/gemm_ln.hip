@@ -261,6 +261,294 @@ __global__ __launch_bounds__(LNG_THREADS, 2) void gemm_ln_kernel(const GemmLnPar
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Band variant: ONE workgroup per CU, each owning an equal band of rows (cfg B: 50432 rows / 256 CUs = 197 = one frame),
+// 8 waves as 4 (rows) x 2 (column halves), the main loop of gemm_big.hip (whole-line operand units, two phases per
+// 64-deep K-tile, ping-pong wave halves, counted vmcnt, no address arithmetic in the loop), then the tail above.
+// Why: with 128-row blocks the 394 workgroups of cfg B land two or one to a CU, and a 24-stage loop in a 4-wave
+// workgroup spends most of its life between a barrier, 8 fragment reads and 12 MFMAs.  Here every CU gets the same
+// rows, the 13..16 row groups of a band go 4 / 3 / 3 / 3 to the wave rows (a missing fourth group is not multiplied),
+// and a phase is 24 MFMAs behind the partner half's reads.
+// LDS: A0 / A1 = the first / second 32 rows of every wave row (128 rows x 128 B, 16 KiB), B0 / B1 = the W rows of column
+// half 0 / 1 (96 x 128 B, 12 KiB; 12 DMA pieces for 8 waves: waves 4..7 request one of theirs twice), two sets: 112 KiB.
+constexpr int LNB_THREADS = 512, LNB_AUNIT = 16384;
+constexpr int lnb_vmcnt(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
+
+template <int BN>      // D = 192
+__global__ __launch_bounds__(LNB_THREADS, 1) void gemm_ln_band_kernel(const GemmLnParams p, int nwg) {
+  constexpr int WN = BN / 2, NT = WN / 16, NP = NT / 2, MT = 4, BMT = 256;
+  constexpr int BUNIT = WN * 128, BPIECES = BUNIT / 1024;          // 12 KiB, 12 pieces
+  constexpr int SET = 2 * LNB_AUNIT + 2 * BUNIT;
+  static_assert(BN == 192, "12 B pieces over 8 waves");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, half = wave >> 2;       // half: the ping-pong group (wave rows 0,1 | 2,3)
+  const int g = lane >> 4, c16 = lane & 15, ch = lane >> 4;
+  const bool odd = (g & 1) != 0;
+  constexpr int N = BN;
+  // this workgroup's band and its row groups: 4 / 3 / 3 / 3 (13) ... 4 / 4 / 4 / 4 (16)
+  const int r0 = (int)((long)blockIdx.x * p.M / nwg), r1 = (int)((long)(blockIdx.x + 1) * p.M / nwg);
+  const int ngroups = (r1 - r0 + 15) >> 4;
+  const int gbase = ngroups >> 2, grem = ngroups & 3;
+  const int gcount = gbase + (wm < grem ? 1 : 0);                  // row groups of this wave row (3 or 4)
+  const int gstart = wm * gbase + min(wm, grem);
+  const int row0 = r0 + gstart * 16;                               // first row of this wave's tile
+  const IqRng rng = p.drop_on ? rng_resolve(p.rng) : p.rng;       // oldest entry of the vector-memory queue
+
+  // ---- unit requests: uniform base + per-lane offsets (bytes) -----------------------------------------------------------------
+  unsigned offA[2][2], offB[2][2];                                 // [half-unit][piece]
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    {
+      const int ur = (wave * 2 + i) * 8 + (lane >> 3);             // unit row 0..127: wave row ur >> 5 (= this wave's), row ur & 31
+      const int gch = ((lane & 7) ^ ((ur >> 1) & 7)) * 16;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        offA[h][i] = (unsigned)(min(row0 + h * 32 + (ur & 31), r1 - 1) * p.lda * 2 + gch);
+    }
+    {
+      int piece = wave + 8 * i;
+      if (piece >= BPIECES) piece = wave;                          // waves 4..7: their first piece again (uniform counts)
+      const int ur = piece * 8 + (lane >> 3);                      // 0..95
+      const int gch = ((lane & 7) ^ ((ur >> 1) & 7)) * 16;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) offB[j][i] = (unsigned)((j * WN + ur) * p.ldb * 2 + gch);
+    }
+  }
+  const char* baseA = reinterpret_cast<const char*>(p.A);
+  const char* baseB = reinterpret_cast<const char*>(p.B);
+  int iset = 0, ikt = 0;
+  auto issue_a = [&](int h) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(baseA + ikt * 128 + offA[h][i]),
+                                       (lds_void_t*)(smem + iset * SET + h * LNB_AUNIT + (wave * 2 + i) * 1024), 16, 0, 0);
+  };
+  auto issue_b = [&](int j) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int piece = wave + 8 * i;
+      if (piece >= BPIECES) piece = wave;
+      __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(baseB + ikt * 128 + offB[j][i]),
+                                       (lds_void_t*)(smem + iset * SET + 2 * LNB_AUNIT + j * BUNIT + piece * 1024), 16, 0, 0);
+    }
+  };
+  const int total = p.K / 64;                                      // K-tiles (>= 2: host)
+  // prologue: K-tile 0 whole, A0 B0 of K-tile 1
+  issue_a(0); issue_b(0); issue_b(1); issue_a(1);
+  iset = 1; ikt = 1;
+  issue_a(0); issue_b(0);
+  __builtin_amdgcn_s_waitcnt(lnb_vmcnt(6));                        // A0 B0 B1 of K-tile 0 landed
+  __builtin_amdgcn_s_barrier();
+  if (half == 1) __builtin_amdgcn_s_barrier();                     // half 1 runs one phase-half behind
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[4], bfr[NT * 2];     // A fragments [row group of the half-unit][k-step]; B fragments [column tile][k-step]
+  int cset = 0;
+  auto read_a = [&](int h) {
+    const unsigned char* U = smem + cset * SET + h * LNB_AUNIT;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int ur = wm * 32 + it * 16 + c16;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) af[it * 2 + s] = *reinterpret_cast<const bf16x8*>(U + ur * 128 + (((s * 4 + ch) ^ ((ur >> 1) & 7)) << 4));
+    }
+  };
+  auto read_b = [&]() {
+    const unsigned char* U = smem + cset * SET + 2 * LNB_AUNIT + wn * BUNIT;
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+      const int ur = ct * 16 + c16;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) bfr[ct * 2 + s] = *reinterpret_cast<const bf16x8*>(U + ur * 128 + (((s * 4 + ch) ^ ((ur >> 1) & 7)) << 4));
+    }
+  };
+  auto wait_left = [&](int left) {
+    if (left == 8) __builtin_amdgcn_s_waitcnt(lnb_vmcnt(8));
+    else if (left == 6) __builtin_amdgcn_s_waitcnt(lnb_vmcnt(6));
+    else if (left == 2) __builtin_amdgcn_s_waitcnt(lnb_vmcnt(2));
+    else if (left == 0) __builtin_amdgcn_s_waitcnt(lnb_vmcnt(0));
+  };
+  auto sync_a = [&](int left) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (half == 1) wait_left(left);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto sync_b = [&](int left) {
+    if (half == 0) wait_left(left);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const bool four = gcount > 3;                                    // wave-uniform: this wave row has a fourth row group
+  for (int q = 0; q < total; ++q) {
+    const bool more1 = q + 1 < total, more2 = q + 2 < total;
+    // phase X: row groups 0, 1 of every wave; requests B1, A1 of K-tile q+1
+    read_b();
+    read_a(0);
+    if (more1) { issue_b(1); issue_a(1); iset ^= 1; ++ikt; }
+    sync_a(more1 ? 8 : 0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          acc[it][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ct * 2 + s], af[it * 2 + s], acc[it][ct], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    sync_b(more1 ? 8 : 0);
+    // phase Y: row groups 2, (3); requests A0, B0 of K-tile q+2
+    read_a(1);
+    if (more2) { issue_a(0); issue_b(0); }
+    sync_a(more2 ? 6 : more1 ? 2 : -1);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        acc[2][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ct * 2 + s], af[s], acc[2][ct], 0, 0, 0);
+    if (four) {
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          acc[3][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ct * 2 + s], af[2 + s], acc[3][ct], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    sync_b(more2 ? 6 : more1 ? 2 : -1);
+    cset ^= 1;
+  }
+  if (half == 0) __builtin_amdgcn_s_barrier();                     // matches half 1's extra barrier: every wave has left the ring
+
+  // ---- tail (the arithmetic of gemm_ln_kernel above, 4 wave rows) --------------------------------------------------------------
+  const int col0 = wn * WN;
+  auto col_of = [&](int jp) { return col0 + (odd ? (2 * jp + 1) * 16 + 4 * (g - 1) : (2 * jp) * 16 + 4 * g); };
+  bool rowok[MT];
+  f32x4 bias_lo[NP], bias_hi[NP];
+  bf16x8 res[MT][NP];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) rowok[i] = i < gcount && row0 + i * 16 + c16 < r1;
+#pragma unroll
+  for (int jp = 0; jp < NP; ++jp) {
+    const int col = col_of(jp);
+    bias_lo[jp] = *reinterpret_cast<const f32x4*>(p.bias + col);
+    bias_hi[jp] = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int gm = min(row0 + i * 16 + c16, r1 - 1);
+      res[i][jp] = *reinterpret_cast<const bf16x8*>(p.residual + (long)gm * p.ldr + col);
+    }
+  }
+  // pass 1: z = dropout(acc + bias) + residual, rounded to bf16, stored; the rounded values replace the accumulators
+  float rsum[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int gm = row0 + i * 16 + c16;
+    rsum[i] = 0.f;
+#pragma unroll
+    for (int jp = 0; jp < NP; ++jp) {
+      float w[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float va = acc[i][2 * jp][r], vb = acc[i][2 * jp + 1][r];
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
+        w[r] = __uint_as_float(sw[0]) + bias_lo[jp][r];
+        w[4 + r] = __uint_as_float(sw[1]) + bias_hi[jp][r];
+      }
+      const int col = col_of(jp);
+      if (p.drop_on) {
+        const uint32_t keep = dropout_keep8(rng, (uint64_t)((long)gm * N + col) >> 3, p.thresh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = ((keep >> e) & 1u) ? w[e] * p.dscale : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w[e] += (float)res[i][jp][e];
+      const bf16x8 zb = pack8(w);
+      if (rowok[i]) *reinterpret_cast<bf16x8*>(p.Z + (long)gm * N + col) = zb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float lo = (float)zb[r], hi = (float)zb[4 + r];
+        acc[i][2 * jp][r] = lo;
+        acc[i][2 * jp + 1][r] = hi;
+        rsum[i] += lo + hi;
+      }
+    }
+    rsum[i] += __shfl_xor(rsum[i], 16, 64);
+    rsum[i] += __shfl_xor(rsum[i], 32, 64);      // this wave's half of the row, on all 4 lanes that share it
+  }
+  // exchange between the two column-half waves of a wave row: red[pass][wn][wave row][row]
+  float* red = reinterpret_cast<float*>(smem);
+  if (g == 0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) red[wn * BMT + wm * 64 + i * 16 + c16] = rsum[i];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (raw barrier + lgkmcnt only: the Z stores stay in flight)
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  float mean[MT], rstd[MT];
+  const float invD = 1.0f / (float)N;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    mean[i] = (rsum[i] + red[(1 - wn) * BMT + wm * 64 + i * 16 + c16]) * invD;
+    float qv = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean[i]; qv += d * d; }
+    qv += __shfl_xor(qv, 16, 64);
+    qv += __shfl_xor(qv, 32, 64);
+    rsum[i] = qv;
+  }
+  if (g == 0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) red[2 * BMT + wn * BMT + wm * 64 + i * 16 + c16] = rsum[i];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const float var = (rsum[i] + red[2 * BMT + (1 - wn) * BMT + wm * 64 + i * 16 + c16]) * invD;
+    rstd[i] = 1.0f / sqrtf(var + p.eps);
+    const int gm = row0 + i * 16 + c16;
+    if (wn == 0 && g == 0 && rowok[i]) { p.mean[gm] = mean[i]; p.rstd[gm] = rstd[i]; }
+  }
+  // pass 2: x = gamma * (z - mean) * rstd + beta
+#pragma unroll
+  for (int jp = 0; jp < NP; ++jp) {
+    const int col = col_of(jp);
+    const f32x4 g_lo = *reinterpret_cast<const f32x4*>(p.gamma + col), g_hi = *reinterpret_cast<const f32x4*>(p.gamma + col + 4);
+    const f32x4 b_lo = *reinterpret_cast<const f32x4*>(p.beta + col), b_hi = *reinterpret_cast<const f32x4*>(p.beta + col + 4);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int gm = row0 + i * 16 + c16;
+      float y[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        y[r] = g_lo[r] * ((acc[i][2 * jp][r] - mean[i]) * rstd[i]) + b_lo[r];
+        y[4 + r] = g_hi[r] * ((acc[i][2 * jp + 1][r] - mean[i]) * rstd[i]) + b_hi[r];
+      }
+      if (rowok[i]) *reinterpret_cast<bf16x8*>(p.X + (long)gm * N + col) = pack8(y);
+    }
+  }
+}
+
+// one workgroup per CU (a multiple of 256 workgroups), 13..16 row groups per band; 0 = not this kernel's shape
+static int band_workgroups(int M, int D, int K) {
+  if (D != 192 || K % 64 != 0 || K < 512) return 0;     // (K = 192: 24.7 us against the 4-wave kernel's 22.4 -- three K-tiles leave nothing to overlap)
+  const int nwg = 256 * ((M + 65535) / 65536);
+  const int lo = M / nwg, hi = (M + nwg - 1) / nwg;
+  return (lo > 192 && hi <= 256) ? nwg : 0;
+}
+
 template <int BMT, int BN>
 int launch(const GemmLnParams& p, hipStream_t st) {
   const size_t lds = (size_t)3 * (BMT + BN) * 32 * 2;
@@ -299,6 +587,16 @@ extern "C" int iq_gemm_bf16_ln(const void* A, int lda, const void* W, int ldw, c
   }
   hipStream_t st = (hipStream_t)stream;
   IQ_PROF(IQ_FAM_GEMM_NT, st);
+  if (const int nwg = band_workgroups(M, D, K)) {
+    if ((lda % 64) == 0 && (ldw % 64) == 0 && (((uintptr_t)A | (uintptr_t)W) % 128) == 0) {
+      constexpr int lds = 2 * (2 * LNB_AUNIT + 2 * 96 * 128);
+      auto k = gemm_ln_band_kernel<192>;
+      static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)attr;
+      k<<<nwg, LNB_THREADS, lds, st>>>(p, nwg);
+      return iq_launch_status();
+    }
+  }
   switch (D) {
     case 128: return launch<128, 128>(p, st);
     case 192: return launch<128, 192>(p, st);
