@@ -15,7 +15,7 @@ python3 - "$cfg" "$out" <<'PY'
 import csv, glob, json, collections, sys
 cfg, out_path = sys.argv[1], sys.argv[2]
 def fam_of(k):
-    if "gemm_nt" in k or "gemm_ln" in k or "gemm_chain" in k: return "gemm_nt"
+    if "gemm_nt" in k or "gemm_ln" in k or "gemm_chain" in k or "gemm_big" in k: return "gemm_nt"
     if "wgrad" in k: return "wgrad"
     if "attn_bwd" in k: return "attn_bwd"
     if "attn_fwd" in k: return "attn_fwd"
