@@ -64,7 +64,10 @@ int iq_ln_bwd_partial_rows(int M, int D);
  *   tok>0 : embedding mode, output row = (m/tok)*seq + m%tok + cls_off and pe[(m%tok+cls_off),:]
  *           is added (V/models/encoder.py:42-47).
  *   gate  : v *= (gate[m,n] > 0) ? gate_scale : 0   (ReLU+dropout backward from the saved hidden).
- * K%8==0, N%8==0, lda/ldb/ldc/ldr/ldg in elements and %8==0. */
+ * K%8==0, N%8==0, lda/ldb/ldc/ldr/ldg in elements and %8==0.
+ * The kernel is chosen from the shape; results do not depend on the choice beyond fp32 summation order:
+ *   N%256==0, K%64==0, K>=256 and >= 512 tiles of 256x256 (ViT-Base at its batch): persistent 256x256 tiles
+ *   (gemm_big.hip, 0.85-1.19 PFLOP/s); otherwise 128x{128,64} tiles (gemm_nt.hip); K%32!=0: register-staged fallback. */
 typedef struct iq_epilogue {
   const float* bias;    /* [N] or NULL */
   int relu;
@@ -124,7 +127,11 @@ int iq_gemm_bf16_wgrad(const void* dY, int ldy, const void* X, int ldx, float* d
 
 /* Several weight gradients that share M (the four Linear layers of one encoder layer: what torch.autograd runs as
  * separate addmm nodes behind V/models/blocks/encoder_layer.py:16-36) in ONE launch + ONE slab reduce.  At most 4
- * problems are fused; larger groups / large N*K run one at a time through the same workspace. */
+ * problems are fused; larger groups / large N*K run one at a time through the same workspace.
+ * Fast path (gemm_wgrad_big.hip: LDS-shared 256-row tiles, a problem whose N is the model width computed transposed):
+ * M%64==0, M>=4096, dY / X 128-byte aligned with ldy%64==0 and ldx%64==0, and one column tile of 128, 192 or 256
+ * dividing the shorter side of every problem; anything else runs the wave-private / shared-tile kernels of
+ * gemm_wgrad.hip.  Either way the slabs are summed in a fixed order: results are bit-reproducible run to run. */
 typedef struct iq_wgrad_problem {
   const void* dY; /* bf16 [M, ldy] */
   int ldy;
