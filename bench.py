@@ -330,8 +330,8 @@ def measure(a, config_id, dev, rank, world, steps, warmup, prof_steps, want_cpu)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="B", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--graph", type=int, default=-1, help="hipGraph replay of the step (default: on)")
