@@ -176,3 +176,26 @@ def test_counted_tail_waits_match_the_isa():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "ok:" in r.stdout
+
+
+def test_pingpong_kernels_hold_their_state_in_registers():
+    """gemm_big / wgrad_big / the gemm_ln band kernel count their DMA queue by hand: a spilled register is a scratch
+    reload, i.e. a vmcnt entry the counts do not know (it drained the queue and cost 30 % when it happened) -- the gfx950
+    ISA of those kernels must show no spill and no scratch, and one workgroup's worth of registers (<= 256)."""
+    import re
+    import tempfile
+    csrc = os.path.join(ROOT, "vit-vs-raw-iq_amd", "csrc")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    seen = 0
+    for src, pat in (("gemm_big.hip", "gemm_big_kernel"), ("gemm_wgrad_big.hip", "wgrad_big_kernel"), ("gemm_ln.hip", "gemm_ln_band_kernel")):
+        out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + csrc, "-I" + os.path.join(ROOT, "include"),
+                               "-S", "--cuda-device-only", os.path.join(csrc, src), "-o", out], stderr=subprocess.DEVNULL)
+        text = open(out).read()
+        os.unlink(out)
+        for m in re.finditer(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text, re.S):
+            name, scratch, vgpr, spill = m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))
+            if pat in name:
+                seen += 1
+                assert scratch == 0 and spill == 0 and vgpr <= 256, (name, scratch, vgpr, spill)
+    assert seen == 3 + 3 + 1
