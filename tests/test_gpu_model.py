@@ -336,13 +336,20 @@ FULL = {
                          ffn_hidden=1024, use_cls_token=True, embedding_type="segment", segment_size=16), 128),
     "D_L2": ("vit", dict(in_channels=1, img_size_h=224, img_size_w=224, patch_size=16, num_classes=19, d_model=768,
                          n_head=12, n_layers=2, ffn_hidden=3072), 256),   # 256 x 197 rows = 197 whole 256-row blocks: the full
-}                                                                         # batch runs gemm_big / wgrad_big, its halves the tiled kernels
+                                                                          # batch runs gemm_big / wgrad_big, its halves the tiled kernels
+    # BASELINE configs[3]'s per-GPU share at FULL depth and batch: ViT-Base L12 x 512 frames (global 4096 / 8 GPUs) -- the
+    # 12-layer grouped wgrad_big launches, gemm_big on every Linear, the 23 GB workspace plan, LayerNorm at D = 768
+    "D": ("vit", dict(in_channels=1, img_size_h=224, img_size_w=224, patch_size=16, num_classes=19, d_model=768,
+                      n_head=12, n_layers=12, ffn_hidden=3072), 512),
+}
 
 
 @pytest.mark.parametrize("cid", sorted(FULL))
 def test_full_batch_training_step_properties(cid):
-    """The benchmarked configurations at their benchmarked batch (BASELINE.json configs[1..3]; ViT-Base's share at 2
-    layers), where the oracle cannot follow in seconds -- size-independent properties of one whole training step:
+    """The benchmarked configurations at their benchmarked batch (BASELINE.json configs[1..3]; ViT-Base's per-GPU share
+    at 2 layers x 256 frames and at its full 12 layers x 512 frames) -- size-independent properties of one whole training
+    step (the gradient itself is compared with the oracle at these batches in
+    test_benchmarked_batch_gradient_matches_oracle):
       * every gradient is finite and the gradient norm is positive;
       * the flat gradient does not depend on the order of the frames in the batch (frames are independent; the
         weight-gradient sums run in a different order, so equality is to fp32 summation error, not bit exact);
@@ -391,3 +398,73 @@ def test_full_batch_training_step_properties(cid):
         del tr, mm
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), f"{cid}: graph replay diverged from eager on {k}"
+
+
+@pytest.mark.parametrize("cid", ["B", "C"])
+def test_benchmarked_batch_gradient_matches_oracle(cid):
+    """BASELINE configs[1] / configs[2] at the batch bench.py times (256 frames per GPU), dropout off: logits, loss and
+    EVERY per-parameter gradient against the CPU oracle's O.loss_and_grads on the same seeded weights and frames, at the
+    limits of the small-batch fixtures.  The batch-2 fixtures never reach ragged row tiles (256 x 197 = 394 x 128 rows),
+    the band variant of the GEMM + LayerNorm kernel (one frame per CU), the M-splits of the weight-gradient tiles or tiles
+    that straddle frames; this does.  (The oracle needs ~2 s for cfg C and ~8 s for cfg B on the box's host cores.)"""
+    d = dev()
+    kind, kw, B = FULL[cid]
+    cfg = O.OracleConfig(kind=kind, drop_prob=0.0, **kw)
+    sd = O.init_state(cfg, 5)
+    m = build(kind, kw)
+    m.load_state_dict(sd)
+    m.to(d).train()
+    g = torch.Generator().manual_seed(6)
+    shape = (B, kw["in_channels"], kw["img_size_h"], kw["img_size_w"]) if kind == "vit" else (B, kw["in_channels"], kw["seq_length"])
+    x = torch.randn(*shape, generator=g)
+    y = torch.randint(0, kw["num_classes"], (B,), generator=g)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref_logits, ref_loss, gref = O.loss_and_grads(cfg, sd, x, y, 0.1)
+    out = m(x.to(d))
+    loss = torch.nn.functional.cross_entropy(out, y.to(d), label_smoothing=0.1)
+    loss.backward()
+    lim_logit = {"B": 5e-2, "C": 4e-2}[cid]                       # the DEEP limits of the same geometries' fixtures
+    err = (out.detach().cpu() - ref_logits).abs().max().item()
+    assert err <= lim_logit, f"{cid}@{B}: logits max err {err:.4g}"
+    assert abs(loss.item() - float(ref_loss)) <= LOSS_ATOL
+    total_ref = math.sqrt(sum(float(v.double().pow(2).sum()) for v in gref.values()))
+    total = math.sqrt(sum(float(p.grad.double().pow(2).sum()) for p in m.parameters()))
+    assert abs(total - total_ref) <= 0.03 * total_ref, (total, total_ref)
+    worst = (0.0, None)
+    for k, p in m.named_parameters():
+        r = gref[k].double()
+        e = (p.grad.cpu().double() - r).norm().item()
+        lim = grad_rel(k) * r.norm().item() + GRAD_ABS_OF_TOTAL * total_ref
+        worst = max(worst, (e / lim, k))
+        assert e <= lim, f"{cid}@{B}: grad {k}: ||err|| {e:.4g} > {lim:.4g} (||ref|| {r.norm().item():.4g})"
+    print(f"{cid}@{B}: logits err {err:.3g}, worst gradient at {worst[0]:.2f} of its limit ({worst[1]})")
+
+
+def test_backward_beyond_65536_rows():
+    """D = 192 with B*S > 65536 rows (cfg B geometry, 384 frames x 197 tokens = 75,648): the fused data-gradient GEMM +
+    LayerNorm backward writes one gamma/beta partial row per 128-row block, more than the stand-alone kernel's 512-block
+    cap -- the plan must size the partial-row scratch for it.  The batch gradient equals the mean of its thirds."""
+    d = dev()
+    kind, kw, _ = FULL["B"]
+    kw = dict(kw, n_layers=2)
+    torch.manual_seed(31)
+    m = build(kind, kw).to(d).train()
+    g = torch.Generator().manual_seed(32)
+    B = 384
+    x = torch.randn(B, 1, 224, 224, generator=g).to(d)
+    y = torch.randint(0, kw["num_classes"], (B,), generator=g).to(d)
+
+    def flat_grad(xb, yb):
+        for p in m.parameters():
+            p.grad = None
+        torch.nn.functional.cross_entropy(m(xb), yb, label_smoothing=0.1).backward()
+        return torch.cat([p.grad.reshape(-1) for p in m.parameters()]).double()
+
+    g_all = flat_grad(x, y)
+    assert torch.isfinite(g_all).all() and g_all.norm().item() > 0
+    t = B // 3
+    g_thirds = (flat_grad(x[:t], y[:t]) + flat_grad(x[t:2 * t], y[t:2 * t]) + flat_grad(x[2 * t:], y[2 * t:])) / 3
+    rel = ((g_all - g_thirds).norm() / g_all.norm()).item()
+    assert rel < 2e-3, rel
+    gam = m.encoder.layers[0].norm1.gamma.grad
+    assert torch.isfinite(gam).all() and gam.abs().sum().item() > 0

@@ -120,3 +120,16 @@ def test_normalization_stats_and_reference_preprocessing():
     assert img.shape == (5, 1, 32, 64) and seq.shape == (5, 2, 1024)
     assert np.array_equal(img.reshape(5, 2, 1024), seq)                 # same numbers, two views ([I;Q] concat == (2, len))
     assert abs(float(seq[:, 0].mean())) < 0.2
+
+
+def test_checkpoint_with_foreign_objects_is_refused_with_a_pointer_to_trust(tmp_path):
+    """The reference's save_checkpoint stores `history` / `config` as given (V/training/utils.py:573-618): numpy
+    scalars there make the file unreadable for the safe loader.  load_checkpoint must say so and name trust=True,
+    never unpickle silently."""
+    import torch
+    from vit_vs_raw_iq_amd import checkpoint as CK
+    path = tmp_path / "ref_style.pth"
+    torch.save({"epoch": 3, "model_state_dict": {}, "val_loss": np.float64(0.25),
+                "history": {"val_acc": [np.float32(0.5)]}, "config": {"root": tmp_path}}, path)
+    with pytest.raises(RuntimeError, match="trust=True"):
+        CK.load_checkpoint(path, model=None)

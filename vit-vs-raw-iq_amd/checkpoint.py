@@ -80,7 +80,17 @@ def load_checkpoint(filepath, model, trainer=None, optimizer=None, scheduler=Non
     """A checkpoint holds tensors, numbers, strings, lists and dicts only, so it is read with the loader that executes
     nothing from the file (weights_only=True) -- reference-trained and third-party .pth files are not trusted code.
     `trust=True` falls back to full unpickling for a file you wrote yourself that carries other Python objects."""
-    ckpt = torch.load(filepath, map_location="cpu", weights_only=not trust)
+    try:
+        ckpt = torch.load(filepath, map_location="cpu", weights_only=not trust)
+    except Exception as exc:       # pickle.UnpicklingError from the weights_only loader
+        if trust:
+            raise
+        raise RuntimeError(
+            f"{filepath}: the safe loader (weights_only=True) refused this checkpoint: {exc}\n"
+            "A checkpoint whose `history` / `config` hold other Python objects (numpy scalars, paths, classes; the "
+            "reference's save_checkpoint stores whatever it is given) is only readable by unpickling, which executes "
+            "code from the file.  If you wrote the file yourself, pass trust=True; nothing is unpickled silently."
+        ) from exc
     model.load_state_dict(ckpt["model_state_dict"])
     if trainer is not None:
         trainer.plan.mark_dirty()

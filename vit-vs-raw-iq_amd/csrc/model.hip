@@ -225,7 +225,11 @@ WsPlan plan_ws(const iq_model* m, int B) {
   mx(iq_wgrad_ws_bytes((int)MT, (int)D, m->Ppad));
   w.wgrad_ws_bytes = wb;
   w.wgrad_ws = take(wb);
-  for (int k = 0; k < 2; ++k) w.ln_part[k] = take(iq_ln_bwd_ws_bytes((int)D));   // norm2 / norm1 partial rows, reduced with the layer's slabs
+  // norm2 / norm1 partial rows, reduced with the layer's slabs: the stand-alone kernel caps its grid (one row per
+  // block), the fused data-gradient GEMM + LayerNorm backward writes one row per row block of M
+  const size_t ln_rows_fused = (size_t)iq_gemm_lnbwd_partial_rows((int)M) * 2 * D * sizeof(float);
+  const size_t ln_bytes = ln_rows_fused > iq_ln_bwd_ws_bytes((int)D) ? ln_rows_fused : iq_ln_bwd_ws_bytes((int)D);
+  for (int k = 0; k < 2; ++k) w.ln_part[k] = take(ln_bytes);
   w.embw_scratch = take((size_t)D * m->Ppad * 4 + 256);
   w.total = cur;
   return w;
@@ -562,8 +566,6 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
   // whole rows (D = 128 | 192): norm1's in the FFN1 data gradient of the same layer, norm2's in the QKV data gradient of
   // the layer ABOVE (the top layer's comes from the head and keeps the stand-alone kernel).
   const bool fuse1 = iq_gemm_lnbwd_supported(D, F) != 0, fuse2 = iq_gemm_lnbwd_supported(D, 3 * D) != 0;
-  const size_t ln_ws_need = (size_t)iq_gemm_lnbwd_partial_rows(M) * 2 * D * sizeof(float);
-  if ((fuse1 || fuse2) && ln_ws_need > iq_ln_bwd_ws_bytes(D)) return fail(m, IQ_ERR_UNSUPPORTED, "backward: batch too large for the LayerNorm partial rows");
   for (int sidx = (stage_hi > Lr ? Lr : stage_hi); sidx >= 1 && sidx >= stage_lo; --sidx) {
     const int l = sidx - 1;
     const LayerOff& o = m->L[l];

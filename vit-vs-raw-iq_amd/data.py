@@ -246,3 +246,43 @@ class DeviceInputPipeline:
     def __call__(self, frames: np.ndarray):
         self.submit(frames)
         return self.get()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The accuracy-reproduction task of SURVEY 8(d) metric (2) / BASELINE.json "top-1 accuracy is reproduced on the same
+# synthetic IQ set": one definition shared by the GPU run (accuracy.py), the CPU oracle run (oracle/accuracy_oracle.py),
+# bench.py's `accuracy` object and tests/test_gpu_trainer.py.
+# ----------------------------------------------------------------------------------------------------------------
+ACCURACY_TASKS = {
+    # cfg A (BASELINE configs[0]; geometry of V/test_model.py:26-55): ViT 32x32, patch 16, 11 classes, D128/H8/L2/F512
+    "vit_A": dict(kind="vit", wd=1e-3,
+                  kw=dict(in_channels=1, img_size_h=32, img_size_w=32, patch_size=16, num_classes=11, d_model=128,
+                          n_head=8, n_layers=2, ffn_hidden=512)),
+    # the raw-IQ geometry of R/test_model.py:91-114: 2x1024, segment 64, cls token, 11 classes, D128/H8/L2/F512
+    "rawiq_R": dict(kind="rawiq", wd=1e-4,
+                    kw=dict(in_channels=2, seq_length=1024, num_classes=11, d_model=128, n_head=8, n_layers=2,
+                            ffn_hidden=512, use_cls_token=True, embedding_type="segment", segment_size=64)),
+}
+ACCURACY_HYPER = dict(n_frames=1000, n_train=800, data_seed=42, init_seed=11, batch=100, steps=240, lr=1e-3, drop_prob=0.1,
+                      fresh_frames=4004, fresh_seed=43)
+
+
+def accuracy_task(name: str):
+    """N = 1000 frames (800 train / 200 held out), seed 42, the first 11 class names, SNR in {-8, 0, 8, 20} dB,
+    z-score from the frames themselves; the ViT image is the first 512 I | first 512 Q samples viewed 32x32
+    (`to_vit_images`), the raw-IQ input the transposed frame.  A second held-out set of 4004 FRESH frames (seed 43, same
+    statistics) shrinks the sampling error of the accuracy estimate from +-0.028 (200 frames) to +-0.006.
+    Returns dict(kind, kw, wd, xtr, ytr, xte, yte, xfresh, yfresh, hyper, chance) of torch CPU tensors."""
+    import torch
+    t = ACCURACY_TASKS[name]
+    h = ACCURACY_HYPER
+    classes = CLASSES[: t["kw"]["num_classes"]]
+    X, Y, _ = make_dataset(h["n_frames"], seed=h["data_seed"], classes=classes)
+    mean, std = zscore_stats(X)
+    XF, YF, _ = make_dataset(h["fresh_frames"], seed=h["fresh_seed"], classes=classes)
+    conv = (lambda A: to_vit_images(A, mean, std, 32, 32)) if t["kind"] == "vit" else (lambda A: to_rawiq(A, mean, std))
+    R, RF = torch.from_numpy(conv(X)), torch.from_numpy(conv(XF))
+    Yt, YFt = torch.from_numpy(Y), torch.from_numpy(YF)
+    n = h["n_train"]
+    return dict(name=name, kind=t["kind"], kw=dict(t["kw"]), wd=t["wd"], xtr=R[:n], ytr=Yt[:n], xte=R[n:], yte=Yt[n:],
+                xfresh=RF, yfresh=YFt, hyper=dict(h), chance=1.0 / len(classes))

@@ -473,7 +473,10 @@ def _parent_of(encoder):
     return parent if parent is not None and getattr(parent, "encoder", None) is encoder else None
 
 
-def _run(plan: NativePlan, owner: nn.Module, src, want):
+def _run(plan: NativePlan, owner: nn.Module, src, want, training=None):
+    """`training` = the flag of the module that was CALLED (an encoder reached through its parent's plan obeys its own
+    train()/eval() state, as Encoder.forward does in the reference); default: the owner's."""
+    training = owner.training if training is None else bool(training)
     names, params = [], []
     for n, p in owner.named_parameters():
         names.append(n)
@@ -481,8 +484,8 @@ def _run(plan: NativePlan, owner: nn.Module, src, want):
     needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
     if needs_grad:
         plan.ensure(src.device)      # re-home BEFORE autograd records the parameter tensors
-        return _PlanFn.apply(plan, src, owner.training, want, tuple(names), *params)
-    logits, enc = plan.forward(src, owner.training, want == "logits", want == "enc")
+        return _PlanFn.apply(plan, src, training, want, tuple(names), *params)
+    logits, enc = plan.forward(src, training, want == "logits", want == "enc")
     return logits if want == "logits" else enc
 
 
@@ -536,7 +539,7 @@ class EncoderViT(nn.Module):
         src = self._expect(src)
         parent = _parent_of(self)
         if parent is not None:           # one plan / one flat parameter buffer per model: run the model's plan
-            return _run(parent.native_plan(), parent, src, "enc")
+            return _run(parent.native_plan(), parent, src, "enc", training=self.training)
         if self._plan is None:
             self._plan = NativePlan(self, self._cfg(), prefix_strip="encoder.")
         return _run(self._plan, self, src, "enc")
@@ -641,7 +644,7 @@ class EncoderRawIQ(nn.Module):
         src = self._expect(src)
         parent = _parent_of(self)
         if parent is not None:           # one plan / one flat parameter buffer per model: run the model's plan
-            return _run(parent.native_plan(), parent, src, "enc")
+            return _run(parent.native_plan(), parent, src, "enc", training=self.training)
         if self._plan is None:
             self._plan = NativePlan(self, self._cfg(), prefix_strip="encoder.")
         return _run(self._plan, self, src, "enc")

@@ -117,9 +117,11 @@ class FusedTrainer:
         self.buckets = make_buckets(self.plan.cfg.n_layers, n_buckets if self.world > 1 else 1)
         self.ranges = [self.plan.grad_range(hi, lo) for hi, lo in self.buckets]
         self.use_graph = bool(use_graph)
-        self._graphs = None          # one hipGraph per segment (see _segments)
-        self._captured = None        # device pointers baked into the captured graphs
-        self._static = None
+        # per batch size: logits / dlogits buffers, static inputs and the captured graphs (one hipGraph per segment, see
+        # _segments) with the device pointers baked into them.  An epoch's last partial batch and the return to the full
+        # batch each find their own slot again instead of discarding every capture twice per epoch.
+        self._slots = {}
+        self._slot = None
         self._logits = None
         self._dlogits = None
         self._batch = 0
@@ -147,11 +149,34 @@ class FusedTrainer:
         self.lr = float(lr)
         self.dyn[0] = self.lr
 
+    MAX_SLOTS = 4        # batch sizes kept captured at once (full batch, epoch tail, a validation-sized one, ...)
+
+    @property
+    def _graphs(self):
+        return self._slot["graphs"] if self._slot is not None else None
+
+    @_graphs.setter
+    def _graphs(self, value):
+        """`trainer._graphs = None` (checkpoint load, hyper-parameter change) drops EVERY capture."""
+        if value is None:
+            for sl in self._slots.values():
+                sl["graphs"] = None
+        elif self._slot is not None:
+            self._slot["graphs"] = value
+
     def _buffers(self, B: int):
         if self._batch != B:
-            K = self.plan.cfg.num_classes
-            self._logits = torch.empty(B, K, dtype=torch.float32, device=self.device)
-            self._dlogits = torch.empty(B, K, dtype=torch.float32, device=self.device)
+            sl = self._slots.pop(B, None)
+            if sl is None:
+                K = self.plan.cfg.num_classes
+                sl = {"logits": torch.empty(B, K, dtype=torch.float32, device=self.device),
+                      "dlogits": torch.empty(B, K, dtype=torch.float32, device=self.device),
+                      "static": None, "graphs": None, "captured": None}
+                while len(self._slots) >= self.MAX_SLOTS:
+                    self._slots.pop(next(iter(self._slots)))          # oldest
+            self._slots[B] = sl                                       # most recent last
+            self._slot = sl
+            self._logits, self._dlogits = sl["logits"], sl["dlogits"]
             self._batch = B
         # every call: an inference forward with a larger batch (evaluate(), model(x)) may have replaced the workspace
         self.plan.workspace(B, self.device)
@@ -232,34 +257,36 @@ class FusedTrainer:
             plan._bind_native(self.gflat)
         plan.generation += 1
         if self.use_graph:
-            if self._graphs is not None and self._captured != self._pointers():
-                self._graphs = None          # a captured buffer moved (workspace regrown by an eval forward, rebinding)
+            sl = self._slot
+            if sl["graphs"] is not None and sl["captured"] != self._pointers():
+                sl["graphs"] = None          # a captured buffer moved (workspace regrown by an eval forward, rebinding)
             if plan.ctr_value != self.steps:
                 plan.step_ctr.fill_(self.steps)      # something else ran a training forward: re-sync the device step
                 plan.ctr_value = self.steps
-            if self._graphs is None:
-                # first call: one eager step on static buffers (this call's step; also warms lazy kernel
-                # attributes and the allocator), then capture the identical launch sequence for later replays
-                if self._static is None or self._static[0].shape != x.shape:
-                    self._static = (torch.empty_like(x), torch.empty_like(y))
-                self._static[0].copy_(x)
-                self._static[1].copy_(y)
-                self._run_segments(self._segments(self._static[0], self._static[1], auto_step=True))
+            if sl["graphs"] is None:
+                # first call at this batch size: one eager step on static buffers (this call's step; also warms lazy
+                # kernel attributes and the allocator), then capture the identical launch sequence for later replays
+                if sl["static"] is None or sl["static"][0].shape != x.shape:
+                    sl["static"] = (torch.empty_like(x), torch.empty_like(y))
+                static = sl["static"]
+                static[0].copy_(x)
+                static[1].copy_(y)
+                self._run_segments(self._segments(static[0], static[1], auto_step=True))
                 torch.cuda.synchronize()
                 graphs = []
-                for seg in self._segments(self._static[0], self._static[1], auto_step=True):
+                for seg in self._segments(static[0], static[1], auto_step=True):
                     g = torch.cuda.CUDAGraph()
                     # thread_local: with a process group alive, its watchdog thread queries events while we capture;
                     # in the default (global) mode that invalidates the capture.  Only this thread's stream is captured.
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         seg()
                     graphs.append(g)
-                self._graphs = graphs
-                self._captured = self._pointers()
+                sl["graphs"] = graphs
+                sl["captured"] = self._pointers()
             else:
-                self._static[0].copy_(x, non_blocking=True)
-                self._static[1].copy_(y, non_blocking=True)
-                self._run_segments([g.replay for g in self._graphs])
+                sl["static"][0].copy_(x, non_blocking=True)
+                sl["static"][1].copy_(y, non_blocking=True)
+                self._run_segments([g.replay for g in sl["graphs"]])
         else:
             self._run_segments(self._segments(x, y, auto_step=False))
         self.steps += 1
