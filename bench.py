@@ -53,7 +53,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16
 RIDGE = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
 FAMILIES = ["gemm_nt", "wgrad", "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd", "misc", "optimizer"]
-PROFILE_ROUND = "r02"        # profiles/<round>_pmc_family_cfg<id>.json holds the PMC passes of this round's kernels
+PROFILE_ROUND = "r03"        # profiles/<round>_pmc_family_cfg<id>.json holds the PMC passes of this round's kernels
 
 
 def geometry(kind, kw):
@@ -135,31 +135,106 @@ def algorithmic_bytes_per_frame(g, B):
     return g["in_elems"] * 2 + 2 * saved + 3 * 4 * param_count(g) / B
 
 
-def cpu_baseline(kind, kw, drop, wd, budget_s=20.0):
-    """The CPU oracle's full training step (dropout ON, clip, AdamW) on this host, bounded sample."""
+def host_cores():
+    """Cores this process may use: the scheduler affinity, cut to the cgroup CPU quota when there is one (a 1-GPU box is a
+    16-core share of a larger host; more threads than that oversubscribe)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    visible = n
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                      # cgroup v2
+            q, period = fh.read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:      # cgroup v1
+                q = int(fh.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                period = int(fh.read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    elif n > 16:
+        n = 16          # no quota readable: a 1-GPU box is documented as a 16-core share of its host
+    return n, visible
+
+
+def cpu_baseline(kind, kw, drop, wd, gpu_batch, budget_s=40.0):
+    """The CPU oracle's full training step (dropout ON, clip, AdamW) on this host's cores, SURVEY 8(d) "CPU baseline beside
+    it": the GPU run's batch -- or, when one step of it would not fit the budget, the largest batch whose step does (stated
+    in `sample`) --, 1 warm-up step + 3 timed steps, torch threads = the cores this process owns (printed)."""
     import torch
     import iq_oracle as O
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    torch.set_num_threads(max(1, min(ncpu, 16)))   # a 1-GPU box owns 16 host cores; more threads oversubscribe (measured)
+    ncpu, visible = host_cores()
+    if os.environ.get("IQ_CPU_THREADS"):
+        ncpu = int(os.environ["IQ_CPU_THREADS"])
+    torch.set_num_threads(max(1, ncpu))
     cfg = O.OracleConfig(kind=kind, drop_prob=drop, **kw)
     sd = O.init_state(cfg, 0)
     st = O.adamw_init(sd)
     g = torch.Generator().manual_seed(0)
-    b = 8 if kw["d_model"] <= 256 else 2
-    shape = (b, kw["in_channels"], kw["img_size_h"], kw["img_size_w"]) if kind == "vit" else (b, kw["in_channels"], kw["seq_length"])
-    x = torch.randn(*shape, generator=g)
-    y = torch.randint(0, kw["num_classes"], (b,), generator=g)
-    O.train_step(cfg, sd, st, x, y, weight_decay=wd)        # warm-up
+
+    def batch_of(b):
+        shape = (b, kw["in_channels"], kw["img_size_h"], kw["img_size_w"]) if kind == "vit" else (b, kw["in_channels"], kw["seq_length"])
+        return torch.randn(*shape, generator=g), torch.randint(0, kw["num_classes"], (b,), generator=g)
+
+    # probe: a small step to size the batch (its time per frame over-estimates the large batch's)
+    pb = min(gpu_batch, 8 if kw["d_model"] <= 256 else 2)
+    x, y = batch_of(pb)
+    O.train_step(cfg, sd, st, x, y, weight_decay=wd)
     t0 = time.perf_counter()
-    n = 0
-    while True:
+    O.train_step(cfg, sd, st, x, y, weight_decay=wd)
+    per_frame = (time.perf_counter() - t0) / pb
+    step_cap = min(60.0, budget_s / 4.0)           # SURVEY 8(d): a step under 60 s; here also 1 + 3 steps inside the budget
+    b = int(max(1, min(gpu_batch, step_cap / per_frame)))
+    x, y = batch_of(b)
+    O.train_step(cfg, sd, st, x, y, weight_decay=wd)        # warm-up at the timed batch
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
         O.train_step(cfg, sd, st, x, y, weight_decay=wd)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 50:
-            break
-    return {"value": round(n * b / el, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} full training steps of batch {b} (same model/config, fp32, dropout on) after 1 warm-up, {el:.1f} s"}
+        times.append(time.perf_counter() - t0)
+    el = sum(times)
+    note = "the GPU run's batch" if b == gpu_batch else f"largest batch with a step under {step_cap:.0f} s (GPU run: {gpu_batch})"
+    print(f"[bench] cpu_baseline: {torch.get_num_threads()} torch threads on {ncpu} usable cores ({visible} visible), batch {b}, "
+          f"steps {', '.join(f'{t:.2f}' for t in times)} s", file=sys.stderr)
+    return {"value": round(3 * b / el, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "cores_visible": visible,
+            "kind": "port", "batch": b, "steps": 3, "warmup": 1,
+            "sample": f"3 full training steps of batch {b} ({note}; same model/config, fp32, dropout on, clip + AdamW) after 1 "
+                      f"warm-up, {el:.1f} s"}
+
+
+def accuracy_reproduction(dev):
+    """SURVEY 8(d) metric (2): top-1 accuracy on the shared synthetic IQ set (data.accuracy_task: cfg A's ViT and the
+    R/test_model.py raw-IQ geometry, N = 1000, 800 / 200, seed 42, fixed step budget), MI355X path vs the CPU oracle from the
+    same initial state.  The oracle half is part of the cpu_baseline leg (rank 0, N = 1 only)."""
+    import torch
+    import accuracy_oracle as AO
+    from vit_vs_raw_iq_amd import accuracy as A
+    from vit_vs_raw_iq_amd import data as D
+    out = {}
+    for name in ("vit_A", "rawiq_R"):
+        task = D.accuracy_task(name)
+        _, sd0 = AO.initial_state(task)
+        t0 = time.perf_counter()
+        gpu = A.train_and_score(task, sd0, device=dev)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        cpu = AO.train_and_score(task)
+        t2 = time.perf_counter()
+        h = task["hyper"]
+        out[name] = {"gpu": {k: round(v, 4) for k, v in gpu.items()}, "cpu_oracle": {k: round(v, 4) for k, v in cpu.items()},
+                     "chance": round(task["chance"], 4), "delta_heldout": round(abs(gpu["heldout"] - cpu["heldout"]), 4),
+                     "delta_fresh": round(abs(gpu["fresh"] - cpu["fresh"]), 4),
+                     "gpu_s": round(t1 - t0, 2), "cpu_s": round(t2 - t1, 2),
+                     "task": f"{h['n_frames']} frames ({h['n_train']} train / {h['n_frames'] - h['n_train']} held out, seed "
+                             f"{h['data_seed']}), {task['kw']['num_classes']} classes, {h['steps']} steps of {h['batch']}, lr {h['lr']}, "
+                             f"dropout {h['drop_prob']}; `fresh` = {h['fresh_frames']} more held-out frames (seed {h['fresh_seed']})"}
+    return out
 
 
 def self_launch(a, argv):
@@ -261,6 +336,24 @@ def measure(a, config_id, dev, rank, world, steps, warmup, prof_steps, want_cpu)
             tr.step(x, y)
         L.iq_prof_collect(ms, cnt)
         L.iq_prof_enable(0)
+        need = L.iq_prof_kernels(None, 0, 0)
+        kbuf = ctypes.create_string_buffer(need + 1)
+        L.iq_prof_kernels(kbuf, need + 1, 1)
+        kernels = []
+        for line in kbuf.value.decode().splitlines():
+            name, fam, n, kms, kbytes, kflops = line.split("\t")
+            n, kms, kbytes, kflops = int(n), float(kms), float(kbytes), float(kflops)
+            if n == 0 or kms <= 0:
+                continue
+            us = kms * 1e3 / n
+            gbs, tfs = kbytes / (kms * 1e-3) / 1e9, kflops / (kms * 1e-3) / 1e12
+            bound = "mfma" if kflops / max(kbytes, 1.0) > RIDGE else "hbm"
+            kernels.append({"kernel": name, "family": FAMILIES[int(fam)], "launches_per_step": round(n / prof_steps, 2),
+                            "avg_us": round(us, 2), "ms_per_step": round(kms / prof_steps, 4),
+                            "algorithmic_bytes_per_launch": int(kbytes / n), "flops_per_launch": int(kflops / n),
+                            "bound": bound, "achieved_gbs": round(gbs, 1), "achieved_tflops": round(tfs, 2),
+                            "frac": round(tfs / MFMA_PEAK_TFLOPS if bound == "mfma" else gbs / HBM_PEAK_GBS, 4)})
+        kernels.sort(key=lambda k: -k["ms_per_step"])
         per_step = {f: ms[i] / prof_steps for i, f in enumerate(FAMILIES)}
         fused_ln = int(cnt[FAMILIES.index("ln_fwd")]) == 0
         work = family_work(geo, B, drop > 0, fused_ln, int(cnt[FAMILIES.index("ln_bwd")]) // prof_steps)
@@ -295,6 +388,9 @@ def measure(a, config_id, dev, rank, world, steps, warmup, prof_steps, want_cpu)
         roof["launches_per_step"] = launches
         roof["algorithmic_bytes_per_launch"] = int(w["bytes"] / launches)
         roof["family_ms_per_step"] = {f: round(v, 4) for f, v in per_step.items()}
+        # the five kernels (not families) that take the most time per step, under the names rocprofv3 --kernel-trace --stats
+        # prints (profiles/*_kernel_stats_*.csv): each with its own algorithmic bytes / flops per launch and roofline fraction
+        roof["kernels"] = kernels[:5]
         tot = sum(per_step.values())
         print(f"[bench:{config_id}] kernel time per step by family (HIP events, eager): "
               + ", ".join(f"{f} {v:.3f} ms" for f, v in per_step.items()) + f"; sum {tot:.3f} ms", file=sys.stderr)
@@ -306,7 +402,7 @@ def measure(a, config_id, dev, rank, world, steps, warmup, prof_steps, want_cpu)
 
     cpu = None
     if rank == 0 and want_cpu:
-        cpu = cpu_baseline(kind, kw, drop, wd, budget_s=a.cpu_budget)
+        cpu = cpu_baseline(kind, kw, drop, wd, B, budget_s=a.cpu_budget)
     del tr, model
     torch.cuda.empty_cache()
     if rank != 0:
@@ -340,7 +436,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the raw-IQ (cfg C) measurement beside cfg B")
     ap.add_argument("--prof-steps", type=int, default=5)
-    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-oracle work per configuration")
+    ap.add_argument("--cpu-budget", type=float, default=40.0, help="seconds of CPU-oracle work per configuration (1 warm-up + 3 timed steps)")
+    ap.add_argument("--no-accuracy", action="store_true", help="skip the accuracy reproduction (cfg A ViT + raw-IQ test geometry, GPU vs CPU oracle)")
     ap.add_argument("--drop", type=float, default=-1.0, help="override the config's dropout probability (diagnostics)")
     a = ap.parse_args()
 
@@ -381,6 +478,10 @@ def main():
         second = measure(a, "C", dev, rank, world, a.steps, a.warmup, a.prof_steps,
                          want_cpu=(world == 1 and not a.no_cpu_baseline))
 
+    acc = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.no_accuracy and a.config == "B" and a.batch == 0:
+        acc = accuracy_reproduction(dev)
+
     if rank == 0:
         out = {
             "metric": "IQ frames/sec training (fwd+loss+bwd+clip+AdamW)", "value": main_res["value"], "unit": "frames/s",
@@ -391,6 +492,8 @@ def main():
             "dist": {"backend": backend, "rccl_ranks": world if backend == "nccl" else 0, "ranks": world},
             "roofline": main_res["roofline"], "cpu_baseline": main_res["cpu_baseline"],
         }
+        if acc is not None:
+            out["accuracy"] = acc
         if second is not None:
             out["secondary"] = {"metric": out["metric"], "unit": "frames/s", **second}
         print(json.dumps(out))

@@ -282,6 +282,11 @@ int iq_model_forward(iq_model_t* m, const float* src, int batch, void* workspace
  * n_layers+1 (head) ... 1 (layer 0) ... 0 (embedding); call with (n_layers+1, 0) for everything. */
 int iq_model_backward(iq_model_t* m, const float* dlogits, const float* denc, int batch, void* workspace,
                       size_t ws_bytes, int accumulate, int stage_hi, int stage_lo, iq_stream_t stream);
+/* Gradient exchange: SURVEY.md 8(b) lists iq_comm_{init, allreduce_bucket, finalize} among the entry points.  They are
+ * deliberately NOT part of this library: BASELINE.json's north_star keeps the host in PyTorch-ROCm, whose
+ * torch.distributed (backend "nccl" = RCCL over xGMI) already owns communicators, streams and the process group.  The C
+ * ABI ends at "this contiguous range of the flat gradient is complete on the stream" (iq_model_backward by stages +
+ * iq_model_grad_range below); vit-vs-raw-iq_amd/trainer.py issues one asynchronous all-reduce per range. */
 /* flat-gradient range [*off, *off+*len) written by stages [stage_lo, stage_hi] (DDP buckets) */
 int iq_model_grad_range(const iq_model_t* m, int stage_hi, int stage_lo, size_t* off, size_t* len);
 
@@ -294,6 +299,12 @@ int iq_model_grad_range(const iq_model_t* m, int stage_hi, int stage_lo, size_t*
 #define IQ_PROF_FAMILIES 8
 int iq_prof_enable(int on);
 int iq_prof_collect(double* ms, long long* count);
+/* Per-KERNEL sums of everything iq_prof_collect has gathered since the last reset: one text line per kernel name (the
+ * name rocprofv3 --kernel-trace --stats prints, without its namespace):
+ *   name \t family \t launches \t total ms \t total algorithmic bytes \t total flops \n
+ * (algorithmic bytes / flops of a launch are computed at its launch site from the problem sizes: operands read once,
+ * results written once).  Returns the length of the full text; writes at most cap-1 bytes + a terminating 0. */
+size_t iq_prof_kernels(char* out, size_t cap, int reset);
 
 #ifdef __cplusplus
 }

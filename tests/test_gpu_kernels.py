@@ -213,7 +213,7 @@ def test_gemm_big_tiles(L, M, N_, K):
 
 
 @pytest.mark.parametrize("D,K", [(192, 192), (192, 768), (128, 128), (128, 1024), (256, 256), (256, 1024), (128, 64)])
-@pytest.mark.parametrize("M,pdrop", [(1000, 0.0), (50432, 0.1), (130, 0.25), (77, 0.0)])
+@pytest.mark.parametrize("M,pdrop", [(1000, 0.0), (50432, 0.1), (130, 0.25), (77, 0.0), (16640, 0.2)])   # 16,640 = cfg C at 256 frames: 64-row blocks
 def test_gemm_with_fused_layernorm_tail_equals_gemm_then_layernorm(L, D, K, M, pdrop):
     """iq_gemm_bf16_ln (out-projection / FFN2 + dropout + residual + LayerNorm in one launch, encoder_layer.py:24-25,32-33)
     against the two-kernel path it replaces (iq_gemm_bf16_nt with the same epilogue, then iq_ln_fwd): Z bit for bit
@@ -258,7 +258,7 @@ def test_gemm_with_fused_layernorm_tail_equals_gemm_then_layernorm(L, D, K, M, p
 
 
 @pytest.mark.parametrize("D,K", [(192, 768), (192, 576), (128, 1024), (128, 384), (128, 64)])
-@pytest.mark.parametrize("M,pdrop", [(1000, 0.0), (50432, 0.1), (130, 0.25), (77, 0.0)])
+@pytest.mark.parametrize("M,pdrop", [(1000, 0.0), (50432, 0.1), (130, 0.25), (77, 0.0), (16640, 0.2)])
 def test_dgrad_with_fused_layernorm_backward_equals_gemm_then_ln_bwd(L, D, K, M, pdrop):
     """iq_gemm_bf16_lnbwd (FFN1 / QKV data gradient + residual + the LayerNorm backward that consumes it, one launch)
     against the two launches it replaces (iq_gemm_bf16_nt with the residual, then iq_ln_bwd): dZ and dY bit for bit
@@ -287,7 +287,7 @@ def test_dgrad_with_fused_layernorm_backward_equals_gemm_then_ln_bwd(L, D, K, M,
     # fused
     dz1 = torch.full_like(z, float("nan")); dy1 = torch.zeros_like(z)
     rows = L.iq_gemm_lnbwd_partial_rows(M)
-    assert rows == (M + 127) // 128
+    assert rows == ((M + 127) // 128 if M > 320 * 128 else (M + 63) // 64)      # 64-row blocks while 128-row ones would not fill the chip
     part = torch.full((rows, 2 * D), float("nan"), device=dev())
     N.check(L.iq_gemm_bf16_lnbwd(A.data_ptr(), K, W.data_ptr(), K, R.data_ptr(), D, z.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                  gamma.data_ptr(), C.byref(dr) if pdrop > 0 else None, dz1.data_ptr(), dy1.data_ptr(),
@@ -613,6 +613,9 @@ def attn_ref(qkv, Bf, S, H, dh):
 
 @pytest.mark.parametrize("S,H,dh,Bf", [(5, 8, 16, 3), (17, 2, 32, 2), (65, 8, 16, 4), (129, 8, 16, 2), (65, 8, 32, 2),
                                        (197, 3, 64, 3), (33, 2, 64, 2), (1025, 8, 16, 1), (224, 1, 64, 1),
+                                       # per-frame kernels (S <= 128 and the frame's images fit LDS): more heads than waves,
+                                       # whole 32-row tiles, the largest S they take
+                                       (40, 12, 16, 2), (96, 4, 32, 3), (128, 8, 16, 2), (64, 3, 64, 5),
                                        # backward keeps the staged side in LDS in chunks (conv1d embedding, S = 1025)
                                        (1025, 8, 32, 1), (1025, 4, 64, 1), (481, 2, 64, 1), (700, 2, 32, 2)])
 def test_attention_fwd_bwd(L, S, H, dh, Bf):

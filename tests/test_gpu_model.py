@@ -443,7 +443,8 @@ def test_benchmarked_batch_gradient_matches_oracle(cid):
 def test_backward_beyond_65536_rows():
     """D = 192 with B*S > 65536 rows (cfg B geometry, 384 frames x 197 tokens = 75,648): the fused data-gradient GEMM +
     LayerNorm backward writes one gamma/beta partial row per 128-row block, more than the stand-alone kernel's 512-block
-    cap -- the plan must size the partial-row scratch for it.  The batch gradient equals the mean of its thirds."""
+    cap -- the plan must size the partial-row scratch for it.  The batch gradient equals the mean of its halves (halves,
+    not thirds: a power-of-two loss scale keeps every bf16 rounding of the activation gradients identical)."""
     d = dev()
     kind, kw, _ = FULL["B"]
     kw = dict(kw, n_layers=2)
@@ -462,9 +463,9 @@ def test_backward_beyond_65536_rows():
 
     g_all = flat_grad(x, y)
     assert torch.isfinite(g_all).all() and g_all.norm().item() > 0
-    t = B // 3
-    g_thirds = (flat_grad(x[:t], y[:t]) + flat_grad(x[t:2 * t], y[t:2 * t]) + flat_grad(x[2 * t:], y[2 * t:])) / 3
-    rel = ((g_all - g_thirds).norm() / g_all.norm()).item()
+    t = B // 2
+    g_halves = (flat_grad(x[:t], y[:t]) + flat_grad(x[t:], y[t:])) / 2
+    rel = ((g_all - g_halves).norm() / g_all.norm()).item()
     assert rel < 2e-3, rel
     gam = m.encoder.layers[0].norm1.gamma.grad
     assert torch.isfinite(gam).all() and gam.abs().sum().item() > 0

@@ -104,6 +104,7 @@ SIGNATURES = {
     "iq_model_grad_range": (_I, [_P, _I, _I, C.POINTER(_Z), C.POINTER(_Z)]),
     "iq_prof_enable": (_I, [_I]),
     "iq_prof_collect": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "iq_prof_kernels": (_Z, [C.c_char_p, _Z, _I]),
 }
 
 _lib = None

@@ -22,6 +22,8 @@
 // accumulator tiles hold and what tr_frag() fetches.
 // LDS images are [rows][dh+16] bf16 (32 B pad: conflict-free transposed reads, 2-way on row reads).
 // Softmax statistics fp32, exp2 domain.  dh in {16,32,64}; dh=16 zero-pads the QK^T contraction.
+#include <stdlib.h>
+
 #include "common.h"
 #include "iqvit.h"
 #include "prof.h"
@@ -510,6 +512,431 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const bf16* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Per-FRAME kernels for short sequences (cfg C: S = 65, 8 heads of 16)
+// ---------------------------------------------------------------------------------------------
+// One workgroup per (frame, head) is the wrong shape when S is a few 32-row tiles: at S = 65 the forward has 3 query tiles
+// for 8 waves, the backward 5 key units / 3 query blocks, every workgroup stages 65 x 32-byte row pieces of q, k and v out
+// of 768-byte rows, and 2,048 such workgroups cost a launch round each (0.8-0.9 TB/s, 0.10 of peak in round 2).
+// Here ONE workgroup owns a frame: its packed qkv rows [S][3D] are one contiguous block of global memory, staged once
+// with fully coalesced 16-byte loads into an LDS image [spad][3D + 16] (row stride = 32 B mod 256 B: the row-fragment
+// ds_read_b128 and the transposing ds_read_b64_tr_b16 are both conflict-free), and wave w then runs heads w, w + 8, ...
+// entirely on its own: same products, same orientation, same softmax arithmetic as the kernels above, no barrier after
+// the staging one.  Query / key halves that are pure padding (S = 65: rows 80..95) are skipped.
+template <int DH>
+__device__ __forceinline__ bf16x8 row_frag_img(const bf16* tile, int ld, int row, int s, int lane) {
+  const int d0 = s * 32 + 8 * (lane >> 4);
+  bf16x8 v = {};
+  if (DH >= 32 || d0 < DH) v = *reinterpret_cast<const bf16x8*>(tile + row * ld + d0);
+  return v;
+}
+
+// rows [0, spad) x `cols` elements (cols % 8 == 0) of a contiguous [S][cols] global block -> LDS image with row stride ld;
+// rows >= S are zero-filled.  UN loads in flight per thread.
+template <int UN>
+__device__ __forceinline__ void stage_block(bf16* img, int ld, const bf16* src, int cols, int S, int spad, int tid, int nthr) {
+  const int cpr = cols >> 3, total = spad * cpr, live = S * cpr;
+  for (int base = 0; base < total; base += UN * nthr) {
+    bf16x8 v[UN];
+#pragma unroll
+    for (int j = 0; j < UN; ++j) {
+      const int id = min(base + j * nthr + tid, live - 1);
+      v[j] = *reinterpret_cast<const bf16x8*>(src + (long)id * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < UN; ++j) {
+      const int id = base + j * nthr + tid;
+      if (id < total) {
+        const int r = id / cpr, c = id - r * cpr;
+        *reinterpret_cast<bf16x8*>(img + r * ld + c * 8) = id < live ? v[j] : bf16x8{};
+      }
+    }
+  }
+}
+
+// G = query tiles of a head that one wave carries through the key sweep TOGETHER: their softmax chains (MFMA -> max ->
+// shuffles -> exp2 -> pack -> MFMA) are independent, so the compiler interleaves them -- with one tile at a time and two
+// waves per SIMD the sweep was a serial dependency chain (15 us for cfg C's 256 frames) -- and a key block's K / V
+// fragments are read from LDS once for all of them.
+template <int DH, int G>
+__global__ __launch_bounds__(ATT_THREADS) void attn_frame_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                                     float* __restrict__ lse, int S, int H, int spad,
+                                                                     float scale_log2) {
+  using C = AttCfg<DH>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16* img = reinterpret_cast<bf16*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+  const int nwave = blockDim.x >> 6;
+  const int b = blockIdx.x;
+  const int D = H * DH, ld = 3 * D + 16;
+  stage_block<8>(img, ld, qkv + (long)b * S * 3 * D, 3 * D, S, spad, tid, blockDim.x);
+  __syncthreads();
+  const int qtiles = (S + 31) / 32;
+  for (int h = wave; h < H; h += nwave) {
+    const bf16* Qs = img + h * DH;
+    const bf16* Ks = Qs + D;
+    const bf16* Vs = Qs + 2 * D;
+    for (int qt0 = 0; qt0 < qtiles; qt0 += G) {
+      bf16x8 qf[G][2][C::KS];
+      f32x4 o[G][2][C::DT];
+      float m[G][2], lsum[G][2];
+      bool live[G][2];                              // wave-uniform: this 16-query half holds at least one real query
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int q0 = (qt0 + t) * 32 + u * 16;
+          live[t][u] = q0 < S;
+          m[t][u] = NEG_BIG; lsum[t][u] = 0.f;
+#pragma unroll
+          for (int s = 0; s < C::KS; ++s) qf[t][u][s] = row_frag_img<DH>(Qs, ld, min(q0 + c16, spad - 1), s, lane);
+#pragma unroll
+          for (int dt = 0; dt < C::DT; ++dt) o[t][u][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      for (int kb = 0; kb < spad; kb += 32) {
+        const bool k1 = kb + 16 < S;                // wave-uniform: the second 16 keys of the block are not all padding
+        bf16x8 kf[2][C::KS], vt[C::DT];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int s = 0; s < C::KS; ++s) kf[kt][s] = row_frag_img<DH>(Ks, ld, kb + kt * 16 + c16, s, lane);
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) vt[dt] = tr_frag(Vs, ld, kb, dt * 16, lane);
+#pragma unroll
+        for (int t = 0; t < G; ++t)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (!live[t][u]) continue;
+            f32x4 sc[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+              f32x4 a = {0.f, 0.f, 0.f, 0.f};
+              if (kt == 0 || k1) {
+#pragma unroll
+                for (int s = 0; s < C::KS; ++s) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][s], qf[t][u][s], a, 0, 0, 0);
+              }
+              sc[kt] = a;
+            }
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+              if (kt == 1 && !k1) { sc[1] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int key = kb + kt * 16 + 4 * g + r;
+                const float x = key < S ? sc[kt][r] : NEG_BIG;
+                sc[kt][r] = x;
+                mx = fmaxf(mx, x);
+              }
+            }
+            mx = group4_max(mx) * scale_log2;
+            const float mn = fmaxf(m[t][u], mx);
+            const float alpha = fast_exp2(m[t][u] - mn);
+            m[t][u] = mn;
+            float rs = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+              if (kt == 1 && !k1) continue;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float pv = fast_exp2(fmaf(sc[kt][r], scale_log2, -mn));
+                sc[kt][r] = pv;
+                rs += pv;
+              }
+            }
+            lsum[t][u] = lsum[t][u] * alpha + rs;
+            const bf16x8 pb = pack_b(sc[0], sc[1]);
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) {
+              o[t][u][dt] *= alpha;
+              o[t][u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[dt], pb, o[t][u][dt], 0, 0, 0);
+            }
+          }
+      }
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (!live[t][u]) continue;
+          const float l = group4_sum(lsum[t][u]);
+          const float inv = 1.0f / l;
+          const int q = (qt0 + t) * 32 + u * 16 + c16;
+          if (q < S) {
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) {
+              bf16x4 w;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) w[r] = (bf16)(o[t][u][dt][r] * inv);
+              *reinterpret_cast<bf16x4*>(out + ((long)b * S + q) * D + h * DH + dt * 16 + 4 * g) = w;
+            }
+            if (g == 0) lse[((long)b * H + h) * S + q] = (m[t][u] + log2f(l)) * LN2;
+          }
+        }
+    }
+  }
+}
+
+// Backward of the same: qkv image + dO image [spad][D + 16] + per-head lse / delta rows, everything staged once; wave w
+// runs phase A (16-key units: dK, dV) and phase B (32-query blocks: dQ) of heads w, w + 8, ... from the images, UG key
+// units / QG query blocks at a time (independent chains for the scheduler, shared fragment reads), as the forward does.
+template <int DH, int UG, int QG>
+__global__ __launch_bounds__(ATT_THREADS) void attn_frame_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                                     const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                                     bf16* __restrict__ dqkv, int S, int H, int spad, float scale) {
+  using C = AttCfg<DH>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+  const int nwave = blockDim.x >> 6;
+  const int b = blockIdx.x;
+  const int D = H * DH, ld = 3 * D + 16, ldo = D + 16;
+  bf16* img = reinterpret_cast<bf16*>(smem);
+  bf16* dimg = img + spad * ld;
+  float* lse_s = reinterpret_cast<float*>(dimg + spad * ldo);    // [H][spad], pre-multiplied by log2(e)
+  float* del_s = lse_s + H * spad;                                // [H][spad]
+  const long ldg = 3L * D;
+  const float scale_log2 = scale * LOG2E;
+  // delta[h][q] = sum_d dO * O over the head's columns (O: its only use, straight from global memory; consecutive threads
+  // take consecutive heads of one row: coalesced 2 * DH-byte pieces) and lse -- requested first, consumed after the images
+  // are written, so that all of the kernel's input is in flight at once
+  for (int id = tid; id < spad * H; id += blockDim.x) {
+    const int q = id / H, h = id - q * H;
+    float dl = 0.f, ls = 0.f;
+    if (q < S) {
+      const bf16* orow = out + ((long)b * S + q) * D + h * DH;
+      const bf16* drow = dout + ((long)b * S + q) * D + h * DH;
+#pragma unroll
+      for (int c = 0; c < C::CPR; ++c) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(drow + c * 8);
+        const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(orow + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)a[e] * (float)o8[e];
+      }
+      ls = lse[((long)b * H + h) * S + q] * LOG2E;
+    }
+    del_s[h * spad + q] = dl;
+    lse_s[h * spad + q] = ls;
+  }
+  stage_block<8>(img, ld, qkv + (long)b * S * ldg, 3 * D, S, spad, tid, blockDim.x);
+  stage_block<4>(dimg, ldo, dout + (long)b * S * D, D, S, spad, tid, blockDim.x);
+  __syncthreads();
+  bf16* dqb = dqkv + (long)b * S * ldg;
+  const int nunit = (S + 15) / 16, nblk = spad / 32;
+  for (int h = wave; h < H; h += nwave) {
+    const bf16* Qs = img + h * DH;
+    const bf16* Ks = Qs + D;
+    const bf16* Vs = Qs + 2 * D;
+    const bf16* Os = dimg + h * DH;
+    const float* lq_s = lse_s + h * spad;
+    const float* dl_s = del_s + h * spad;
+    // ---- phase A: 16 keys on the lanes, sweep the queries: dV^T, dK^T ------------------------------------------------
+    for (int un0 = 0; un0 < nunit; un0 += UG) {
+      bf16x8 kf[UG][C::KS], vf[UG][C::KS];
+      f32x4 dv[UG][C::DT], dk[UG][C::DT];
+#pragma unroll
+      for (int j = 0; j < UG; ++j) {
+        const int row = min((un0 + j) * 16 + c16, spad - 1);
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s) {
+          kf[j][s] = row_frag_img<DH>(Ks, ld, row, s, lane);
+          vf[j][s] = row_frag_img<DH>(Vs, ld, row, s, lane);
+        }
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) { dv[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      }
+      for (int ql = 0; ql < spad; ql += 32) {
+        const bool u1 = ql + 16 < S;                      // wave-uniform: second 16 queries not all padding
+        bf16x8 qa[2][C::KS], da[2][C::KS], doT[C::DT], qT[C::DT];
+        f32x4 lq4[2], dl4[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+          for (int s = 0; s < C::KS; ++s) {
+            qa[u][s] = row_frag_img<DH>(Qs, ld, ql + u * 16 + c16, s, lane);
+            da[u][s] = row_frag_img<DH>(Os, ldo, ql + u * 16 + c16, s, lane);
+          }
+          lq4[u] = *reinterpret_cast<const f32x4*>(lq_s + ql + u * 16 + 4 * g);
+          dl4[u] = *reinterpret_cast<const f32x4*>(dl_s + ql + u * 16 + 4 * g);
+        }
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+          doT[dt] = tr_frag(Os, ldo, ql, dt * 16, lane);
+          qT[dt] = tr_frag(Qs, ld, ql, dt * 16, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < UG; ++j) {
+          const int unit = un0 + j;
+          if (unit >= nunit) continue;                    // wave-uniform
+          const int key = unit * 16 + c16;
+          const bool unit_partial = unit * 16 + 16 > S;   // wave-uniform
+          f32x4 p[2], ds[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !u1) { p[1] = f32x4{0.f, 0.f, 0.f, 0.f}; ds[1] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < C::KS; ++s) {
+              sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[u][s], kf[j][s], sa, 0, 0, 0);
+              dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[u][s], vf[j][s], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              // padded QUERY rows: Q = dO = 0 and lse = delta = 0, so P = 1 and dS = 0 multiply zeros; padded KEYS are masked
+              float pv = fast_exp2(sa[r] * scale_log2 - lq4[u][r]);
+              if (unit_partial) pv = key < S ? pv : 0.f;
+              p[u][r] = pv;
+              ds[u][r] = pv * (dp[r] - dl4[u][r]) * scale;
+            }
+          }
+          const bf16x8 pB = pack_b(p[0], p[1]), dsB = pack_b(ds[0], ds[1]);
+#pragma unroll
+          for (int dt = 0; dt < C::DT; ++dt) {
+            dv[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doT[dt], pB, dv[j][dt], 0, 0, 0);
+            dk[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT[dt], dsB, dk[j][dt], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < UG; ++j) {
+        const int key = (un0 + j) * 16 + c16;
+        if (un0 + j < nunit && key < S) {
+#pragma unroll
+          for (int dt = 0; dt < C::DT; ++dt) {
+            bf16x4 wk, wv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { wk[r] = (bf16)dk[j][dt][r]; wv[r] = (bf16)dv[j][dt][r]; }
+            *reinterpret_cast<bf16x4*>(dqb + (long)key * ldg + D + h * DH + dt * 16 + 4 * g) = wk;
+            *reinterpret_cast<bf16x4*>(dqb + (long)key * ldg + 2 * D + h * DH + dt * 16 + 4 * g) = wv;
+          }
+        }
+      }
+    }
+    // ---- phase B: 32 queries on the lanes, sweep the keys: dQ^T ------------------------------------------------------
+    for (int qb0 = 0; qb0 < nblk; qb0 += QG) {
+      bf16x8 qf[QG][2][C::KS], dof[QG][2][C::KS];
+      float lq[QG][2], dl[QG][2];
+      bool live[QG][2];
+      f32x4 dq[QG][C::DT][2];
+#pragma unroll
+      for (int t = 0; t < QG; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int q0 = (qb0 + t) * 32 + u * 16;
+          live[t][u] = q0 < S;
+          const int q = min(q0 + c16, spad - 1);
+#pragma unroll
+          for (int s = 0; s < C::KS; ++s) {
+            qf[t][u][s] = row_frag_img<DH>(Qs, ld, q, s, lane);
+            dof[t][u][s] = row_frag_img<DH>(Os, ldo, q, s, lane);
+          }
+          lq[t][u] = lq_s[q];
+          dl[t][u] = dl_s[q];
+#pragma unroll
+          for (int dt = 0; dt < C::DT; ++dt) dq[t][dt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      for (int kl = 0; kl < spad; kl += 32) {
+        const bool kblk_partial = kl + 32 > S;            // wave-uniform
+        const bool k1 = kl + 16 < S;
+        bf16x8 ka[2][C::KS], va[2][C::KS], kT[C::DT];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int s = 0; s < C::KS; ++s) {
+            ka[kt][s] = row_frag_img<DH>(Ks, ld, kl + kt * 16 + c16, s, lane);
+            va[kt][s] = row_frag_img<DH>(Vs, ld, kl + kt * 16 + c16, s, lane);
+          }
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) kT[dt] = tr_frag(Ks, ld, kl, dt * 16, lane);
+#pragma unroll
+        for (int t = 0; t < QG; ++t)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (!live[t][u]) continue;
+            f32x4 ds[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+              if (kt == 1 && !k1) { ds[1] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
+              f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int s = 0; s < C::KS; ++s) {
+                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[kt][s], qf[t][u][s], sa, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[kt][s], dof[t][u][s], dp, 0, 0, 0);
+              }
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int key = kl + kt * 16 + 4 * g + r;
+                float pv = fast_exp2(sa[r] * scale_log2 - lq[t][u]);
+                if (kblk_partial) pv = key < S ? pv : 0.f;
+                ds[kt][r] = pv * (dp[r] - dl[t][u]) * scale;
+              }
+            }
+            const bf16x8 dsB = pack_b(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt)
+              dq[t][dt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[dt], dsB, dq[t][dt][u], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int t = 0; t < QG; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int q = (qb0 + t) * 32 + u * 16 + c16;
+          if (live[t][u] && q < S) {
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) {
+              bf16x4 w;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) w[r] = (bf16)dq[t][dt][u][r];
+              *reinterpret_cast<bf16x4*>(dqb + (long)q * ldg + h * DH + dt * 16 + 4 * g) = w;
+            }
+          }
+        }
+    }
+  }
+}
+
+// LDS bytes of the per-frame kernels; 0 = not their shape (sequence too long for one image)
+constexpr size_t ATT_FRAME_LDS_MAX = 112 * 1024;   // larger frames measured no faster than (frame, head) workgroups (profiles/r03_probes.txt)
+inline size_t frame_fwd_lds(int S, int H, int dh) {
+  const int spad = (S + 31) / 32 * 32;
+  return (size_t)spad * (3 * H * dh + 16) * 2;
+}
+inline size_t frame_bwd_lds(int S, int H, int dh) {
+  const int spad = (S + 31) / 32 * 32;
+  return (size_t)spad * (3 * H * dh + 16) * 2 + (size_t)spad * (H * dh + 16) * 2 + (size_t)2 * H * spad * sizeof(float);
+}
+// Per-frame when the (frame, head) kernels would idle most of their 8 waves: at most 4 query tiles.  IQ_TUNE_ATTN_FRAME=0|1
+// forces the choice where both apply (probes).
+inline bool use_frame(int S, size_t lds) {
+  static const int tune = [] { const char* e = getenv("IQ_TUNE_ATTN_FRAME"); return e ? atoi(e) : -1; }();
+  if (lds > ATT_FRAME_LDS_MAX) return false;
+  if (tune == 0) return false;
+  if (tune == 1) return true;
+  return S <= 128;
+}
+
+template <int DH>
+int launch_frame_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, hipStream_t st) {
+  const int spad = (S + 31) / 32 * 32;
+  const size_t lds = frame_fwd_lds(S, H, DH);
+  auto k = attn_frame_fwd_kernel<DH, (DH == 64 ? 2 : 4)>;
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int threads = 64 * (H < ATT_WAVES ? H : ATT_WAVES);
+  k<<<B, threads, lds, st>>>((const bf16*)qkv, (bf16*)out, lse, S, H, spad, LOG2E / sqrtf((float)DH));
+  return iq_launch_status();
+}
+template <int DH>
+int launch_frame_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int S, int H,
+                     hipStream_t st) {
+  const int spad = (S + 31) / 32 * 32;
+  const size_t lds = frame_bwd_lds(S, H, DH);
+  auto k = attn_frame_bwd_kernel<DH, (DH == 64 ? 2 : 3), (DH == 16 ? 4 : DH == 32 ? 3 : 2)>;
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int threads = 64 * (H < ATT_WAVES ? H : ATT_WAVES);
+  k<<<B, threads, lds, st>>>((const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, S, H, spad,
+                             1.0f / sqrtf((float)DH));
+  return iq_launch_status();
+}
+
 constexpr size_t ATT_LDS_FWD_BUDGET = 72 * 1024;   // S=197, dh=64 (224 rows) in one stage, 2 WG/CU
 constexpr size_t ATT_LDS_BWD_BUDGET = 76 * 1024;   // S=197, dh=64: both 224-row images + statistics, 2 WG/CU
 constexpr int ATT_MAX_S = 4096;                    // lse / delta stay whole in LDS (8 B per padded row)
@@ -592,6 +1019,19 @@ extern "C" int iq_attn_fwd_masked(const void* qkv, void* out, float* lse, const 
   if (mask_hstride != 0 && mask_hstride != (long)S * S) return IQ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   IQ_PROF(IQ_FAM_ATTN_FWD, st);
+  const bool frame = !mask && (dh == 16 || dh == 32 || dh == 64) && use_frame(S, frame_fwd_lds(S, H, dh));
+  {
+    const double rows = (double)B * S, Dm = (double)H * dh;
+    if (frame) IQ_PROF_K(2.0 * rows * 4.0 * Dm + 4.0 * B * H * S, 4.0 * B * H * (double)S * S * dh, "attn_frame_fwd_kernel<%d>", dh);
+    else IQ_PROF_K(2.0 * rows * 4.0 * Dm + 4.0 * B * H * S, 4.0 * B * H * (double)S * S * dh, "attn_fwd_kernel<%d, %s>", dh, mask ? "true" : "false");
+  }
+  if (frame) {
+    switch (dh) {
+      case 16: return launch_frame_fwd<16>(qkv, out, lse, B, S, H, st);
+      case 32: return launch_frame_fwd<32>(qkv, out, lse, B, S, H, st);
+      default: return launch_frame_fwd<64>(qkv, out, lse, B, S, H, st);
+    }
+  }
   return mask ? dispatch_fwd<true>(qkv, out, lse, mask, mask_hstride, B, S, H, dh, st)
               : dispatch_fwd<false>(qkv, out, lse, nullptr, 0, B, S, H, dh, st);
 }
@@ -607,6 +1047,19 @@ extern "C" int iq_attn_bwd_masked(const void* qkv, const void* out, const void* 
   if (mask_hstride != 0 && mask_hstride != (long)S * S) return IQ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   IQ_PROF(IQ_FAM_ATTN_BWD, st);
+  const bool frame = !mask && (dh == 16 || dh == 32 || dh == 64) && use_frame(S, frame_bwd_lds(S, H, dh));
+  {
+    const double rows = (double)B * S, Dm = (double)H * dh;      // qkv, out, dout read; dqkv written; 7 MFMA products
+    if (frame) IQ_PROF_K(2.0 * rows * 8.0 * Dm + 4.0 * B * H * S, 14.0 * B * H * (double)S * S * dh, "attn_frame_bwd_kernel<%d>", dh);
+    else IQ_PROF_K(2.0 * rows * 8.0 * Dm + 4.0 * B * H * S, 14.0 * B * H * (double)S * S * dh, "attn_bwd_kernel<%d, %s>", dh, mask ? "true" : "false");
+  }
+  if (frame) {
+    switch (dh) {
+      case 16: return launch_frame_bwd<16>(qkv, out, dout, lse, dqkv, B, S, H, st);
+      case 32: return launch_frame_bwd<32>(qkv, out, dout, lse, dqkv, B, S, H, st);
+      default: return launch_frame_bwd<64>(qkv, out, dout, lse, dqkv, B, S, H, st);
+    }
+  }
   return mask ? dispatch_bwd<true>(qkv, out, dout, lse, dqkv, mask, mask_hstride, B, S, H, dh, st)
               : dispatch_bwd<false>(qkv, out, dout, lse, dqkv, nullptr, 0, B, S, H, dh, st);
 }

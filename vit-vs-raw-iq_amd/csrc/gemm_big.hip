@@ -251,8 +251,14 @@ bool gemm_big_try(const GemmParams& p0, int epi_mode, hipStream_t st) {
   p.tiles_m = (p.M + BG_BM - 1) / BG_BM;
   p.tiles_n = p.N / BG_BN;
   const int ntiles = p.tiles_m * p.tiles_n;
-  if (ntiles < 512) return false;                          // fewer than two rounds of 256 CUs: the 128 x 128 tiles fill the chip better
-  const int grid = 256;                                    // one workgroup per CU, persistent over its share of the tiles
+  if (ntiles < 512) return false;                          // fewer than two rounds of an MI355X's 256 CUs: the 128 x 128 tiles fill the chip better
+  // one workgroup per CU (128 KiB of LDS each), persistent over its share of the tiles
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  const int grid = cus;
   const size_t lds = (size_t)8 * BG_UNIT;                  // 128 KiB
 #define IQ_BIG_LAUNCH(E)                                                                                              \
   do {                                                                                                                \

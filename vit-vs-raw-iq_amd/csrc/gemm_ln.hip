@@ -17,6 +17,8 @@
 // LayerNorm statistics are taken from the bf16-ROUNDED Z (what backward re-reads), two-pass (mean, then centred sum
 // of squares) in fp32: lane-local sums -> 2 shuffles across the 4 lane groups that share a row -> one LDS exchange
 // between the two column-half waves.  Same arithmetic as ln_fwd_kernel; results agree to fp32 summation order.
+#include <stdlib.h>
+
 #include "common.h"
 #include "gemm_common.h"
 #include "iqvit.h"
@@ -587,6 +589,9 @@ extern "C" int iq_gemm_bf16_ln(const void* A, int lda, const void* W, int ldw, c
   }
   hipStream_t st = (hipStream_t)stream;
   IQ_PROF(IQ_FAM_GEMM_NT, st);
+  // A + W + residual read, Z + X written (+ bias, gamma, beta, statistics)
+  const double work_bytes = 2.0 * ((double)M * K + (double)D * K + 3.0 * (double)M * D) + 12.0 * D + 8.0 * M;
+  const double work_flops = 2.0 * (double)M * D * K;
   if (const int nwg = band_workgroups(M, D, K)) {
     if ((lda % 64) == 0 && (ldw % 64) == 0 && (((uintptr_t)A | (uintptr_t)W) % 128) == 0) {
       constexpr int lds = 2 * (2 * LNB_AUNIT + 2 * 96 * 128);
@@ -594,12 +599,18 @@ extern "C" int iq_gemm_bf16_ln(const void* A, int lda, const void* W, int ldw, c
       static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       (void)attr;
       k<<<nwg, LNB_THREADS, lds, st>>>(p, nwg);
+      IQ_PROF_K(work_bytes, work_flops, "gemm_ln_band_kernel<192>");
       return iq_launch_status();
     }
   }
+  // Row block: 128, or 64 where 128-row blocks would leave CUs without a workgroup (cfg C: M = 16,640 = 130 blocks of 128
+  // on 256 CUs).  Same K order per row either way: Z / X / statistics are bit-identical.  IQ_TUNE_LN_ROWS forces it (probes).
+  static const int tune_rows = [] { const char* e = getenv("IQ_TUNE_LN_ROWS"); return e ? atoi(e) : 0; }();
+  const bool rows64 = D == 256 || tune_rows == 64 || (tune_rows == 0 && (M + 127) / 128 <= 320);
+  IQ_PROF_K(work_bytes, work_flops, "gemm_ln_kernel<%d, %d>", rows64 ? 64 : 128, D);
   switch (D) {
-    case 128: return launch<128, 128>(p, st);
-    case 192: return launch<128, 192>(p, st);
+    case 128: return rows64 ? launch<64, 128>(p, st) : launch<128, 128>(p, st);
+    case 192: return rows64 ? launch<64, 192>(p, st) : launch<128, 192>(p, st);
     case 256: return launch<64, 256>(p, st);      // 64-row blocks: 128 accumulator + 64 residual registers would spill
     default: return IQ_ERR_UNSUPPORTED;
   }

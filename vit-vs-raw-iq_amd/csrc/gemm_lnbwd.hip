@@ -20,6 +20,8 @@
 // LayerNorm in the MFMA register layout instead (rows spread over two waves, 96 accumulators + 48 Z registers + 96
 // recomputed xhat live at once) spilled 26-98 registers whatever was tried.  The Z rows are requested behind the last
 // ring stage (counted vmcnt), mean / rstd / gamma wait in LDS from the start of the kernel.
+#include <stdlib.h>
+
 #include "common.h"
 #include "gemm_common.h"
 #include "iqvit.h"
@@ -27,7 +29,7 @@
 
 namespace {
 
-constexpr int LB_THREADS = 256, LB_BM = 128;
+constexpr int LB_THREADS = 256;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 
@@ -42,9 +44,9 @@ struct LnBwdParams {
 
 __device__ __forceinline__ int bswz64(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }   // {0,2,3,1}: gemm_nt.hip
 
-template <int BN>
+template <int BMT, int BN>
 __global__ __launch_bounds__(LB_THREADS, 2) void gemm_lnbwd_kernel(const LnBwdParams p) {
-  constexpr int BMT = LB_BM, BK2 = 32, NS = 3;
+  constexpr int BK2 = 32, NS = 3;
   constexpr int WN = BN / 2, NT = WN / 16, NP = NT / 2, MT = BMT / 32;
   constexpr int STAGE_BYTES = (BMT + BN) * BK2 * 2;
   constexpr int A_LD = BMT * BK2 * 2 / (4 * 1024);
@@ -133,7 +135,8 @@ __global__ __launch_bounds__(LB_THREADS, 2) void gemm_lnbwd_kernel(const LnBwdPa
   float* side = reinterpret_cast<float*>(smem + NS * STAGE_BYTES);     // [mean BMT][rstd BMT][gamma N]
   const int sr = tid & (BMT - 1);
   const int sgm = min(m0 + sr, p.M - 1);
-  const float side_v = tid < BMT ? p.mean[sgm] : p.rstd[sgm];
+  float side_v = 0.f;
+  if (tid < 2 * BMT) side_v = tid < BMT ? p.mean[sgm] : p.rstd[sgm];
   f32x4 side_g = {0.f, 0.f, 0.f, 0.f};
   if (tid < N / 4) side_g = *reinterpret_cast<const f32x4*>(p.gamma + tid * 4);
   {
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(LB_THREADS, 2) void gemm_lnbwd_kernel(const LnBwdPa
   }
   issue(0);
   issue(1);
-  side[tid] = side_v;                                    // tid < 128: mean[r] at r; else rstd[r] at 128 + r
+  if (tid < 2 * BMT) side[tid] = side_v;                 // tid < BMT: mean[r] at r; else rstd[r] at BMT + r
   if (tid < N / 4) *reinterpret_cast<f32x4*>(side + 2 * BMT + tid * 4) = side_g;
   const int ch = lane >> 4;
   // main stages: stage ks landed (stage ks+1 stays in flight), barrier, refill the vacated slot
@@ -324,19 +327,32 @@ __global__ __launch_bounds__(LB_THREADS, 2) void gemm_lnbwd_kernel(const LnBwdPa
   }
 }
 
-template <int BN>
+template <int BMT, int BN>
 int launch(const LnBwdParams& p, hipStream_t st) {
-  const size_t lds = (size_t)3 * (LB_BM + BN) * 32 * 2 + (2 * LB_BM + BN) * sizeof(float);   // ring + mean | rstd | gamma
-  auto k = gemm_lnbwd_kernel<BN>;
+  const size_t lds = (size_t)3 * (BMT + BN) * 32 * 2 + (2 * BMT + BN) * sizeof(float);   // ring + mean | rstd | gamma
+  auto k = gemm_lnbwd_kernel<BMT, BN>;
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  k<<<(p.M + LB_BM - 1) / LB_BM, LB_THREADS, lds, st>>>(p);
+  k<<<(p.M + BMT - 1) / BMT, LB_THREADS, lds, st>>>(p);
   return iq_launch_status();
+}
+
+// Row block: 128, or 64 where 128-row blocks would leave CUs without a workgroup (cfg C: M = 16,640 = 130 blocks on 256
+// CUs).  dZ / dY do not depend on it (row-local arithmetic); the gamma / beta partial rows are one per block, so the caller
+// sizes and reduces iq_gemm_lnbwd_partial_rows(M) rows.  IQ_TUNE_LNBWD_ROWS forces it (probes).
+inline int lnbwd_block_rows(int M) {
+  static const int tune_rows = [] { const char* e = getenv("IQ_TUNE_LNBWD_ROWS"); return e ? atoi(e) : 0; }();
+  if (tune_rows == 64 || tune_rows == 128) return tune_rows;
+  return (M + 127) / 128 <= 320 ? 64 : 128;
 }
 
 }  // namespace
 
 extern "C" int iq_gemm_lnbwd_supported(int D, int K) { return ((D == 128 || D == 192) && K >= 64 && K % 32 == 0) ? 1 : 0; }
-extern "C" int iq_gemm_lnbwd_partial_rows(int M) { return M > 0 ? (M + LB_BM - 1) / LB_BM : 0; }
+extern "C" int iq_gemm_lnbwd_partial_rows(int M) {
+  if (M <= 0) return 0;
+  const int r = lnbwd_block_rows(M);
+  return (M + r - 1) / r;
+}
 
 extern "C" int iq_gemm_bf16_lnbwd(const void* A, int lda, const void* Wt, int ldw, const void* residual, int ldr,
                                   const void* z, const float* mean, const float* rstd, const float* gamma,
@@ -361,5 +377,9 @@ extern "C" int iq_gemm_bf16_lnbwd(const void* A, int lda, const void* Wt, int ld
   }
   hipStream_t st = (hipStream_t)stream;
   IQ_PROF(IQ_FAM_GEMM_NT, st);
-  return D == 192 ? launch<192>(p, st) : launch<128>(p, st);
+  // A + Wt + residual + Z read, dZ (+ dY) written
+  IQ_PROF_K(2.0 * ((double)M * K + (double)D * K + (double)M * D * (3 + (p.drop_on ? 1 : 0))) + 8.0 * M, 2.0 * (double)M * D * K,
+            "gemm_lnbwd_kernel<%d, %d>", lnbwd_block_rows(M), D);
+  if (lnbwd_block_rows(M) == 64) return D == 192 ? launch<64, 192>(p, st) : launch<64, 128>(p, st);
+  return D == 192 ? launch<128, 192>(p, st) : launch<128, 128>(p, st);
 }

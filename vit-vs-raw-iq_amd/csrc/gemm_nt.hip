@@ -16,6 +16,8 @@
 // ds_read_b128 fragment reads (16 rows x one chunk column per lane group) bank-conflict free.
 // Epilogue: register-only (see gemm_epilogue): C^T accumulators + v_permlane16_swap give each lane 8
 // consecutive columns of a row.
+#include <stdlib.h>
+
 #include "common.h"
 #include "gemm_common.h"
 #include "iqvit.h"
@@ -413,7 +415,15 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   // Column tile: 128 for wide N, else 64 (the register-staged fallback for K % 32 != 0 uses the same choice).
   const bool wide = (N % 128 == 0 || N > 512);
   const int bn = wide ? 128 : 64;
-  const int bm = BM;
+  // Row tile: 128, or 64 when 128-row tiles would leave CUs idle (three workgroups fit a CU: fewer than 768 tiles is less
+  // than one full round).  cfg C (M = 16,640): the N = 128 data gradient is 130 tiles of 128 x 128, the QKV projection 390.
+  // The 64-row tile streams A once as well (the weight is re-read from L2).  IQ_TUNE_NT_ROWS = 64 | 128 forces it (probes).
+  static const int tune_rows = [] { const char* e = getenv("IQ_TUNE_NT_ROWS"); return e ? atoi(e) : 0; }();
+  int bm = BM;
+  if (async_ok) {
+    const long t128 = (long)((M + 127) / 128) * ((N + bn - 1) / bn);
+    if (tune_rows == 64 || (tune_rows == 0 && t128 < 512)) bm = 64;
+  }
   p.tiles_m = (M + bm - 1) / bm;
   p.tiles_n = (N + bn - 1) / bn;
   const int grid = p.tiles_m * p.tiles_n;
@@ -426,7 +436,15 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
     p.bias = zero_bias();
   }
   p.stagger = 2;      // measured best of {0, 2, 6} (profiles/r01_probes.txt)
-  if (async_ok && gemm_big_try(p, epi_mode, st)) return iq_launch_status();
+  // algorithmic work of this launch (operands read once, result written once; residual / gate tiles read once)
+  const double mn = (double)M * N;
+  const double work_bytes = 2.0 * ((double)M * K + (double)N * K + mn) + (p.residual ? 2.0 * mn : 0.0) + (p.gate ? 2.0 * mn : 0.0) +
+                            (has_bias ? 4.0 * N : 0.0);
+  const double work_flops = 2.0 * mn * K;
+  if (async_ok && gemm_big_try(p, epi_mode, st)) {
+    IQ_PROF_K(work_bytes, work_flops, "gemm_big_kernel<%d>", epi_mode);
+    return iq_launch_status();
+  }
   // C = A W^T + R, nothing else in the tail, whole rows in one 192- / 128-column tile: residual streamed as extra K stages.
   // (the plain 192-column tile reads A once -- N=192 K=768: 27.6 vs 37.3 us -- but lost it all to an exposed residual fetch)
   if (async_ok && epi_mode == EPI_RES && (N == 192 || N == 128) && K >= 384 && !has_bias && !p.relu && !p.drop_on &&
@@ -436,6 +454,7 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
     const size_t lds = (size_t)3 * (BM + N) * 32 * 2;       // <= 60 KiB: under the 64 KiB default cap, no attribute call
     if (N == 192) gemm_nt_async_kernel<128, 192, EPI_RES, true><<<p.tiles_m, GEMM_THREADS, lds, st>>>(p);
     else gemm_nt_async_kernel<128, 128, EPI_RES, true><<<p.tiles_m, GEMM_THREADS, lds, st>>>(p);
+    IQ_PROF_K(work_bytes, work_flops, "gemm_nt_async_kernel<128, %d, 1, true>", N);
     return iq_launch_status();
   }
   // Variants that were measured and not kept (weight-stationary persistent workgroups, wave-private weight-in-registers
@@ -445,7 +464,8 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   const size_t lds_reg = (size_t)(BM + bn) * BK * 2;
 #define IQ_GEMM_LAUNCH(BN_, EPI_)                                                                  \
   do {                                                                                             \
-    if (async_ok) gemm_nt_async_kernel<128, BN_, EPI_><<<grid, GEMM_THREADS, lds_async, st>>>(p);  \
+    if (async_ok && bm == 64) gemm_nt_async_kernel<64, BN_, EPI_><<<grid, GEMM_THREADS, lds_async, st>>>(p);  \
+    else if (async_ok) gemm_nt_async_kernel<128, BN_, EPI_><<<grid, GEMM_THREADS, lds_async, st>>>(p);  \
     else gemm_nt_kernel<BN_, EPI_><<<grid, GEMM_THREADS, lds_reg, st>>>(p);                        \
   } while (0)
 #define IQ_GEMM_EPI(BN_)                                                       \
@@ -460,5 +480,7 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   if (bn == 128) { IQ_GEMM_EPI(128) } else { IQ_GEMM_EPI(64) }
 #undef IQ_GEMM_EPI
 #undef IQ_GEMM_LAUNCH
+  if (async_ok) IQ_PROF_K(work_bytes, work_flops, "gemm_nt_async_kernel<%d, %d, %d, false>", bm, bn, epi_mode);
+  else IQ_PROF_K(work_bytes, work_flops, "gemm_nt_kernel<%d, %d>", bn, epi_mode);
   return iq_launch_status();
 }

@@ -519,8 +519,23 @@ unsigned long long* g_wstamps = nullptr;
 #endif
 
 int launch_reduce(const RedGroup& rg, int nblk, hipStream_t st) {
+  IQ_PROF(IQ_FAM_WGRAD, st);
   wgrad_reduce_kernel<<<nblk, 256, 0, st>>>(rg);
+  if (iq_prof_scope_.on) {
+    double bytes = 0;
+    for (int i = 0; i < rg.nseg; ++i) bytes += 4.0 * rg.s[i].n * (rg.s[i].rows + 1 + (rg.accumulate ? 1 : 0));
+    IQ_PROF_K(bytes, 0.0, "wgrad_reduce_kernel");
+  }
   return IQ_OK;
+}
+
+// algorithmic work of a weight-gradient group: both operands read once, fp32 results written once (slabs excluded)
+void wgrad_work(const iq_wgrad_problem_t* pr, int nprob, int M, double* bytes, double* flops) {
+  *bytes = *flops = 0;
+  for (int i = 0; i < nprob; ++i) {
+    *bytes += 2.0 * M * ((double)pr[i].N + pr[i].K) + 4.0 * (double)pr[i].N * pr[i].K;
+    *flops += 2.0 * M * (double)pr[i].N * pr[i].K;
+  }
 }
 
 int wgrad_shared_one(const iq_wgrad_problem_t& pb, int M, float* ws, int accumulate, hipStream_t st) {
@@ -536,6 +551,8 @@ int wgrad_shared_one(const iq_wgrad_problem_t& pb, int M, float* ws, int accumul
 #endif
   const int grid = w.tiles_n * w.tiles_k * w.splits;
   const size_t lds = (size_t)w.mc * (YLD + w.tk + 16) * 2;
+  {
+  IQ_PROF(IQ_FAM_WGRAD, st);
 #define IQ_WG_LAUNCH(TK_, MC_)                                                                                   \
   do {                                                                                                           \
     auto k = wgrad_kernel<TK_, MC_>;                                                                             \
@@ -545,6 +562,10 @@ int wgrad_shared_one(const iq_wgrad_problem_t& pb, int M, float* ws, int accumul
   if (w.tk == 128) IQ_WG_LAUNCH(128, 64);
   else IQ_WG_LAUNCH(64, 64);
 #undef IQ_WG_LAUNCH
+  double wbytes, wflops;
+  wgrad_work(&pb, 1, M, &wbytes, &wflops);
+  IQ_PROF_K(wbytes, wflops, "wgrad_kernel<%d, 64>", w.tk == 128 ? 128 : 64);
+  }
   RedGroup rg;
   memset(&rg, 0, sizeof(rg));
   const long n = (long)N * K;
@@ -610,12 +631,17 @@ extern "C" int iq_gemm_bf16_wgrad_grouped(const iq_wgrad_problem_t* probs, int n
   }
   if (ws_bytes < iq_wgrad_grouped_ws_bytes(probs, nprob, M, max_workgroups)) return IQ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  IQ_PROF(IQ_FAM_WGRAD, st);
+  double wbytes, wflops;
+  wgrad_work(probs, nprob, M, &wbytes, &wflops);
   WbPlan wb;
   if (nprob > 0 && max_workgroups == 0 && wgrad_big_plan(probs, nprob, M, &wb) && ws_bytes >= wb.floats * sizeof(float)) {
     // LDS-shared 256-row tiles (gemm_wgrad_big.hip): whole 64-row steps, line-aligned operands, one common column tile
     float *slab[PW_MAXP], *bslab[PW_MAXP];
-    wgrad_big_launch(probs, nprob, M, wb, ws, slab, bslab, st);
+    {
+      IQ_PROF(IQ_FAM_WGRAD, st);
+      wgrad_big_launch(probs, nprob, M, wb, ws, slab, bslab, st);
+      IQ_PROF_K(wbytes, wflops, "wgrad_big_kernel<%d>", wb.tk);
+    }
     RedGroup rg;
     memset(&rg, 0, sizeof(rg));
     int nblk = 0;
@@ -687,7 +713,11 @@ extern "C" int iq_gemm_bf16_wgrad_grouped(const iq_wgrad_problem_t* probs, int n
   rg.accumulate = accumulate;
   const size_t lds_pw = (size_t)4 * PW_WAVE_LDS * 2;   // 4 waves x 32 rows x (144 + 80) elements = 56 KiB
   if (lds_pw > 48 * 1024) (void)hipFuncSetAttribute((const void*)wgrad_pw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pw);
-  wgrad_pw_kernel<<<w.ntile * w.splits, PW_THREADS, lds_pw, st>>>(g);
+  {
+    IQ_PROF(IQ_FAM_WGRAD, st);
+    wgrad_pw_kernel<<<w.ntile * w.splits, PW_THREADS, lds_pw, st>>>(g);
+    IQ_PROF_K(wbytes, wflops, "wgrad_pw_kernel");
+  }
   launch_reduce(rg, nblk, st);
   return iq_launch_status();
 }

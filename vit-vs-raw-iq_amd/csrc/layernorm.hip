@@ -252,6 +252,7 @@ extern "C" int iq_ln_fwd(const void* z, const float* gamma, const float* beta, v
   if (!ln_shape(D, &s)) return IQ_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   IQ_PROF(IQ_FAM_LN_FWD, st);
+  IQ_PROF_K(2.0 * (double)M * D * 2 + 8.0 * M, 0.0, "ln_fwd_kernel(D=%d)", D);
   bool ok = ln_dispatch(s, [&](auto lpr, auto nv) {
     constexpr int LPR = decltype(lpr)::value, NV = decltype(nv)::value;
     ln_fwd_kernel<LPR, NV><<<ln_grid(M, (64 / LPR) * 4, LN_FWD_MAX_BLOCKS), LN_THREADS, 0, st>>>((const bf16*)z, gamma, beta, (bf16*)x, mean,
@@ -300,6 +301,7 @@ extern "C" int iq_ln_bwd(const void* dx, const void* z, const float* mean, const
   }
   hipStream_t st = (hipStream_t)stream;
   IQ_PROF(IQ_FAM_LN_BWD, st);
+  IQ_PROF_K(2.0 * (double)M * D * (3 + (dropping ? 1 : 0)) + 8.0 * M, 0.0, "ln_bwd_kernel(D=%d)", D);
   int rc = IQ_OK;
   bool ok = ln_dispatch(s, [&](auto lpr, auto nv) {
     constexpr int LPR = decltype(lpr)::value, NV = decltype(nv)::value;

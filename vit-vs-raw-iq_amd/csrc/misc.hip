@@ -165,33 +165,38 @@ __global__ __launch_bounds__(64) void head_fwd_kernel(const bf16* __restrict__ x
     if (lane == 0) { hstat[2 * b] = mean; hstat[2 * b + 1] = rstd; }
   }
   __syncthreads();
-  if (D <= 256) {
-    // feature (after the affine) in registers: the K dot products then only load W and overlap (reading fh back from
-    // global memory inside the k loop serialised 19 memory round trips: 29 us for 256 frames)
-    float fv[4];
+  if (D % 4 == 0 && D <= 1024) {
+    // The K dot products, K / (kpar * 4) rounds instead of K serial ones (19 dependent memory round trips + wave
+    // reductions took 23-29 us for 256 frames): the feature after the affine goes to LDS, lane group kk = lane / lpk takes
+    // class k0 + kk, its lpk lanes read W[k] as float4 (coalesced), four classes per lane in flight.
+    __shared__ float fs[1024];
+    for (int d = lane; d < D; d += 64) fs[d] = ln_g ? ln_g[d] * fh[d] + ln_b[d] : fh[d];
+    __syncthreads();
+    int lpk = 64;                                   // largest power of two <= min(64, D / 4)
+    while (lpk * 4 > D) lpk >>= 1;
+    if (lpk >= 1) {
+      const int kpar = 64 / lpk, kk = lane / lpk, dl = lane % lpk;
+      for (int k0 = 0; k0 < K; k0 += kpar * 4) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int d = lane + 64 * i;
-      fv[i] = d < D ? (ln_g ? ln_g[d] * fh[d] + ln_b[d] : fh[d]) : 0.f;
-    }
-    for (int k0 = 0; k0 < K; k0 += 4) {
-      float a[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < 4; ++u) {
+          const int k = min(k0 + u * kpar + kk, K - 1);
+          for (int d = 4 * dl; d < D; d += 4 * lpk) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(W + (long)k * D + d);
+            const f32x4 f = *reinterpret_cast<const f32x4*>(fs + d);
+            a[u] += w[0] * f[0] + w[1] * f[1] + w[2] * f[2] + w[3] * f[3];
+          }
+        }
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int k = min(k0 + kk, K - 1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int d = lane + 64 * i;
-          if (d < D) a[kk] += fv[i] * W[(long)k * D + d];
+        for (int u = 0; u < 4; ++u) {
+          float t = a[u];
+          for (int o = lpk >> 1; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+          const int k = k0 + u * kpar + kk;
+          if (dl == 0 && k < K) logits[(long)b * K + k] = t + bias[k];
         }
       }
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const float t = wave_sum(a[kk]);
-        if (lane == 0 && k0 + kk < K) logits[(long)b * K + k0 + kk] = t + bias[k0 + kk];
-      }
+      return;
     }
-    return;
   }
   for (int k = 0; k < K; ++k) {
     float a = 0.f;
@@ -204,7 +209,10 @@ __global__ __launch_bounds__(64) void head_fwd_kernel(const bf16* __restrict__ x
   }
 }
 
-// label-smoothed CE; one block, thread per frame (loops if B > blockDim)
+// label-smoothed CE; one block, thread per frame (loops if B > blockDim).  KMAX > 0: the K <= KMAX logits of a frame are
+// loaded ONCE, all loads in flight together, and every pass runs on registers (three passes of dependent loads and 2 K
+// expf took 13.5 us for 256 frames); KMAX = 0: any K, from memory.
+template <int KMAX>
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                  int B, int K, float smoothing, float denom,
                                                  float* __restrict__ loss_sum, int32_t* __restrict__ n_correct,
@@ -216,26 +224,61 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
     const float* z = logits + (long)b * K;
     const int y = (int)labels[b];
-    float mx = z[0];
-    int am = 0;
-    for (int k = 1; k < K; ++k)
-      if (z[k] > mx) { mx = z[k]; am = k; }
-    float se = 0.f;
-    for (int k = 0; k < K; ++k) se += expf(z[k] - mx);
-    const float lse = mx + logf(se);
-    float sum_logp = 0.f;
-    for (int k = 0; k < K; ++k) sum_logp += z[k] - lse;
     // a label outside [0, K) (torch raises a device-side assert): never read out of bounds; the frame's loss and
     // gradient become NaN so the mistake is loud without taking the GPU context down
     const bool y_ok = y >= 0 && y < K;
-    const float nll = y_ok ? -(z[y] - lse) : __builtin_nanf("");
-    lacc += (1.0f - smoothing) * nll + smoothing * (-sum_logp / (float)K);
-    cacc += (am == y) ? 1 : 0;
-    if (dlogits) {
-      for (int k = 0; k < K; ++k) {
-        const float pk = expf(z[k] - lse);
-        const float tgt = (k == y ? 1.0f - smoothing : 0.f) + smoothing / (float)K;
-        dlogits[(long)b * K + k] = y_ok ? (pk - tgt) / denom : __builtin_nanf("");
+    if constexpr (KMAX > 0) {
+      float zr[KMAX];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) zr[k] = k < K ? z[k] : -3.0e38f;
+      float mx = zr[0];
+      int am = 0;
+#pragma unroll
+      for (int k = 1; k < KMAX; ++k)
+        if (zr[k] > mx) { mx = zr[k]; am = k; }
+      float se = 0.f, sz = 0.f, zy = 0.f;
+      float ek[KMAX];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        ek[k] = k < K ? expf(zr[k] - mx) : 0.f;
+        se += ek[k];
+        sz += k < K ? zr[k] : 0.f;
+        zy = k == y ? zr[k] : zy;
+      }
+      const float lse = mx + logf(se);
+      const float sum_logp = sz - (float)K * lse;
+      const float nll = y_ok ? -(zy - lse) : __builtin_nanf("");
+      lacc += (1.0f - smoothing) * nll + smoothing * (-sum_logp / (float)K);
+      cacc += (am == y) ? 1 : 0;
+      if (dlogits) {
+        const float inv = 1.0f / se;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+          if (k < K) {
+            const float tgt = (k == y ? 1.0f - smoothing : 0.f) + smoothing / (float)K;
+            dlogits[(long)b * K + k] = y_ok ? (ek[k] * inv - tgt) / denom : __builtin_nanf("");
+          }
+        }
+      }
+    } else {
+      float mx = z[0];
+      int am = 0;
+      for (int k = 1; k < K; ++k)
+        if (z[k] > mx) { mx = z[k]; am = k; }
+      float se = 0.f;
+      for (int k = 0; k < K; ++k) se += expf(z[k] - mx);
+      const float lse = mx + logf(se);
+      float sum_logp = 0.f;
+      for (int k = 0; k < K; ++k) sum_logp += z[k] - lse;
+      const float nll = y_ok ? -(z[y] - lse) : __builtin_nanf("");
+      lacc += (1.0f - smoothing) * nll + smoothing * (-sum_logp / (float)K);
+      cacc += (am == y) ? 1 : 0;
+      if (dlogits) {
+        for (int k = 0; k < K; ++k) {
+          const float pk = expf(z[k] - lse);
+          const float tgt = (k == y ? 1.0f - smoothing : 0.f) + smoothing / (float)K;
+          dlogits[(long)b * K + k] = y_ok ? (pk - tgt) / denom : __builtin_nanf("");
+        }
       }
     }
   }
@@ -335,6 +378,61 @@ __global__ __launch_bounds__(256) void head_bwd_w_kernel(const float* __restrict
     } else {
       dln_g[d] = accumulate ? dln_g[d] + ta : ta;
       dln_b[d] = accumulate ? dln_b[d] + tb : tb;
+    }
+  }
+}
+
+// The same gradients for K <= KMAX classes with the LayerNorm row folded in: block = 32 feature columns d x 8 frame
+// slices, every thread keeps T[k] = sum_b dlogits[b,k] * feat_hat[b,d] and s[k] = sum_b dlogits[b,k] for ALL k, so
+//   dW[k,d] = gamma[d] T[k] + beta[d] s[k],  db[k] = s[k],  dgamma[d] = sum_k W[k,d] T[k],  dbeta[d] = sum_k W[k,d] s[k]
+// (the kernel above recomputed d(feat) = dlogits W per (frame, d) for the gamma / beta row: K dependent loads x B/8 frames
+// per thread, 41 us for 256 frames of the raw-IQ head).  Slices are combined through LDS in fixed order.
+template <int KMAX>
+__global__ __launch_bounds__(256) void head_bwd_w2_kernel(const float* __restrict__ dlogits, const float* __restrict__ feat_hat,
+                                                          const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                          const float* __restrict__ W, float* __restrict__ dW, float* __restrict__ db,
+                                                          float* __restrict__ dln_g, float* __restrict__ dln_b, int B, int D, int K,
+                                                          int accumulate) {
+  __shared__ float sT[8][KMAX][33];
+  __shared__ float sS[8][KMAX];
+  const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int d = blockIdx.x * 32 + ol;
+  const bool live = d < D;
+  float T[KMAX], sd[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) { T[k] = 0.f; sd[k] = 0.f; }
+  for (int b = sl; b < B; b += 8) {
+    const float f = live ? feat_hat[(long)b * D + d] : 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const float dl = k < K ? dlogits[(long)b * K + k] : 0.f;      // one address per wave-instruction: a broadcast load
+      T[k] += dl * f;
+      sd[k] += dl;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    sT[sl][k][ol] = T[k];
+    if (ol == 0) sS[sl][k] = sd[k];
+  }
+  __syncthreads();
+  if (sl == 0 && live) {
+    const float g = ln_g ? ln_g[d] : 1.f, be = ln_g ? ln_b[d] : 0.f;
+    float lg = 0.f, lb = 0.f;
+    for (int k = 0; k < K; ++k) {
+      float t = 0.f, sk = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { t += sT[i][k][ol]; sk += sS[i][k]; }
+      const float v = g * t + be * sk;
+      dW[(long)k * D + d] = accumulate ? dW[(long)k * D + d] + v : v;
+      if (d == 0) db[k] = accumulate ? db[k] + sk : sk;
+      const float w = W[(long)k * D + d];
+      lg += w * t;
+      lb += w * sk;
+    }
+    if (ln_g) {
+      dln_g[d] = accumulate ? dln_g[d] + lg : lg;
+      dln_b[d] = accumulate ? dln_b[d] + lb : lb;
     }
   }
 }
@@ -531,7 +629,8 @@ extern "C" int iq_ce_fwd_bwd(const float* logits, const int64_t* labels, int B, 
   IQ_PROF(IQ_FAM_MISC, stream);
   if (B <= 0) return IQ_OK;
   if (!logits || !labels || K <= 0 || denom <= 0.f) return IQ_ERR_ARG;
-  ce_kernel<<<1, 256, 0, (hipStream_t)stream>>>(logits, labels, B, K, smoothing, denom, loss_sum, n_correct, dlogits);
+  if (K <= 32) ce_kernel<32><<<1, 256, 0, (hipStream_t)stream>>>(logits, labels, B, K, smoothing, denom, loss_sum, n_correct, dlogits);
+  else ce_kernel<0><<<1, 256, 0, (hipStream_t)stream>>>(logits, labels, B, K, smoothing, denom, loss_sum, n_correct, dlogits);
   return iq_launch_status();
 }
 
@@ -544,8 +643,12 @@ extern "C" int iq_head_bwd(const float* dlogits, const float* featn, const float
   if (ln_g && (!ln_b || !hstat || !dln_g || !dln_b)) return IQ_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   head_bwd_dx_kernel<<<B, 256, D * sizeof(float), st>>>(dlogits, featn, hstat, ln_g, W, (bf16*)dx, S, D, K, pool);
-  const int n = (K + 1) * D;
-  head_bwd_w_kernel<<<(n + 31) / 32, 256, 0, st>>>(dlogits, featn, ln_g, ln_b, W, dW, db, dln_g, dln_b, B, D, K, accumulate);
+  if (K <= 32) {
+    head_bwd_w2_kernel<32><<<(D + 31) / 32, 256, 0, st>>>(dlogits, featn, ln_g, ln_b, W, dW, db, dln_g, dln_b, B, D, K, accumulate);
+  } else {
+    const int n = (K + 1) * D;
+    head_bwd_w_kernel<<<(n + 31) / 32, 256, 0, st>>>(dlogits, featn, ln_g, ln_b, W, dW, db, dln_g, dln_b, B, D, K, accumulate);
+  }
   return iq_launch_status();
 }
 
