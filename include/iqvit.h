@@ -109,15 +109,19 @@ int iq_gemm_bf16_lnbwd(const void* A, int lda, const void* Wt, int ldw, const vo
                        const float* mean, const float* rstd, const float* gamma, const iq_dropout_t* drop, void* dz,
                        void* dy, float* partial, int M, int D, int K, iq_stream_t stream);
 
-/* Two chained NT GEMMs in one launch: H[M,F] = epi1(X[M,D] * Wa[F,D]^T); Y[M,D] = epi2(H * Wb[D,F]^T).
- * Replaces PositionwiseFeedForward.forward (V/models/layers/position_wise_feed_forward.py:12-17) + dropout2 + residual
- * (V/models/blocks/encoder_layer.py:30-33), and -- with the transposed weight shadows and epi1 = gate -- its data-gradient
- * chain.  H is written once (backward needs it) and consumed from LDS; results are bit-identical to two
- * iq_gemm_bf16_nt calls.  epi1: bias / relu / drop / gate; epi2: bias / drop / residual.  D in {64,128,192,256}, F % 128 == 0. */
-int iq_gemm_chain_supported(int D, int F);
-int iq_gemm_bf16_chain(const void* X, int ldx, const void* Wa, int ldwa, void* H, int ldh, const void* Wb, int ldwb,
-                       void* Y, int ldy, int M, int F, int D, const iq_epilogue_t* epi1, const iq_epilogue_t* epi2,
-                       iq_stream_t stream);
+/* The feed-forward sub-layer of whole FRAMES in one launch (one workgroup per frame of S rows, D in {128, 192},
+ * F % 128 == 0, S <= 224):
+ *   H = dropout1(relu(X1 * W1^T + b1))            bf16 [frames*S, F]  (written once; backward reads it)
+ *   Z = dropout2(H * W2^T + b2) + X1              bf16 [frames*S, D]  (kept for backward)
+ *   X = gamma * (Z - mean) * rstd + beta          bf16 [frames*S, D];  mean, rstd fp32 [frames*S]
+ * = PositionwiseFeedForward.forward (V/models/layers/position_wise_feed_forward.py:12-17) + `x = norm2(dropout2(ffn(x)) + x)`
+ * (V/models/blocks/encoder_layer.py:30-33).  H is consumed from LDS, never re-read from HBM.  H and Z are bit-identical to
+ * iq_gemm_bf16_nt (bias, relu, drop1) followed by iq_gemm_bf16_ln; dropout indices as there (output element row*N + n).
+ * W1 [F, D], W2 [D, F] bf16 row-major; all pointers 16-byte aligned. */
+int iq_ffn_chain_supported(int S, int D, int F);
+int iq_ffn_chain_fwd(const void* X1, const void* W1, const float* b1, const iq_dropout_t* drop1, void* H, const void* W2,
+                     const float* b2, const iq_dropout_t* drop2, const float* gamma, const float* beta, float eps, void* Z,
+                     void* X, float* mean, float* rstd, int frames, int S, int D, int F, iq_stream_t stream);
 
 /* Weight gradient: dW[N,K] (+)= dY[M,N]^T * X[M,K]; dbias[N] (+)= colsum(dY) (NULL to skip).
  * Split over M into slabs in `ws` (iq_wgrad_ws_bytes), reduced deterministically (no atomics). */

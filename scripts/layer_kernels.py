@@ -77,12 +77,25 @@ def wgrad():
     us = timeit(lambda: L.iq_gemm_bf16_wgrad_grouped(probs, 4, M, ws.data_ptr(), nb, 0, 0, None, 0, st()))
     nk = D * F * 2 + D * D * 4
     rec("weight gradients (grouped + reduce)", us, 2 * M * (2 * D + 2 * F + 2 * D + 4 * D) + 4 * nk, 2 * M * nk)
+def ffn_chain():
+    if not L.iq_ffn_chain_supported(S, D, F):
+        return
+    X1 = bf(M, D); W1 = (torch.randn(F, D, device=d) / math.sqrt(D)).bfloat16(); W2 = (torch.randn(D, F, device=d) / math.sqrt(F)).bfloat16()
+    b1 = torch.randn(F, device=d); b2 = torch.randn(D, device=d); gm = torch.rand(D, device=d) + 0.5; bt = torch.randn(D, device=d)
+    Hh = torch.empty(M, F, device=d, dtype=torch.bfloat16); Z = torch.empty(M, D, device=d, dtype=torch.bfloat16); X = torch.empty_like(Z)
+    mean = torch.empty(M, device=d); rstd = torch.empty(M, device=d)
+    d1, d2 = dr(2), dr(3)
+    us = timeit(lambda: L.iq_ffn_chain_fwd(X1.data_ptr(), W1.data_ptr(), b1.data_ptr(), C.byref(d1) if drop > 0 else None, Hh.data_ptr(),
+                                           W2.data_ptr(), b2.data_ptr(), C.byref(d2) if drop > 0 else None, gm.data_ptr(), bt.data_ptr(), 1e-12,
+                                           Z.data_ptr(), X.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, S, D, F, st()))
+    print(f"{'[ffn chain: ffn1 + ffn2 + norm2]':34s} {us:8.1f} us  {(2 * (3 * M * D + M * F + 2 * D * F)) / us / 1e3:8.1f} GB/s  {4 * M * D * F / us / 1e6:8.1f} TFLOP/s", flush=True)
 print(f"D={D} H={H} F={F} S={S} B={B} M={M} drop={drop}")
 nt("qkv projection", 3 * D, D, bias=True)
 tb = attn()
 gemm_ln("out-proj + drop + res + norm1", D, 1)
 nt("ffn1 + relu + drop", F, D, bias=True, relu=True, dropsite=2)
 gemm_ln("ffn2 + drop + res + norm2", F, 3)
+ffn_chain()
 fwd = sum(r[1] for r in rows)
 nt("ffn2 dgrad (gate)", F, D, gate=True)
 gemm_lnbwd("ffn1 dgrad + norm1 bwd", F, 1)

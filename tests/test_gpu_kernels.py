@@ -328,42 +328,70 @@ def _epi(N, **kw):
     return e
 
 
-@pytest.mark.parametrize("M,D,F", [(1000, 192, 768), (130, 128, 256), (64, 64, 128), (777, 256, 512), (50432, 192, 768)])
-def test_gemm_chain_equals_two_gemms(L, M, D, F):
-    """iq_gemm_bf16_chain (FFN forward and its data-gradient chain in one launch) against two iq_gemm_bf16_nt calls:
-    same K order, same rounding of the intermediate, same Philox counters => bit-identical (the residual-only second
-    GEMM excepted, see below)."""
+@pytest.mark.parametrize("frames,S,D,F,pdrop", [(256, 197, 192, 768, 0.1), (7, 197, 192, 768, 0.0), (256, 65, 128, 1024, 0.2),
+                                                 (5, 5, 128, 512, 0.0), (3, 224, 192, 128, 0.3), (9, 17, 128, 256, 0.1),
+                                                 (4, 129, 128, 512, 0.0), (2, 1, 192, 256, 0.0), (100, 197, 192, 64, 0.1),
+                                                 (40, 197, 192, 192, 0.1)])
+def test_ffn_chain_equals_ffn1_then_ffn2_layernorm(L, frames, S, D, F, pdrop):
+    """iq_ffn_chain_fwd (the whole feed-forward sub-layer + norm2 of a frame in one workgroup: position_wise_feed_forward.py:12-17,
+    encoder_layer.py:30-33) against the two launches it replaces -- iq_gemm_bf16_nt (bias, ReLU, dropout1) then iq_gemm_bf16_ln:
+    H and Z bit for bit (same K order, same Philox counters), statistics to fp32 summation order, X within one bf16 ulp; and
+    against fp64 without dropout."""
     N = _N()
-    assert L.iq_gemm_chain_supported(D, F) == 1 and L.iq_gemm_chain_supported(176, F) == 0
+    assert L.iq_ffn_chain_supported(S, D, F) == 1
+    assert L.iq_ffn_chain_supported(S, 256, F) == 0 and L.iq_ffn_chain_supported(S, D, 96) == 0
+    M = frames * S
     g = torch.Generator(device="cuda").manual_seed(M + D + F)
-    X = bf(torch.randn(M, D, device=dev(), generator=g))
-    Wa = bf(torch.randn(F, D, device=dev(), generator=g) / math.sqrt(D))
-    Wb = bf(torch.randn(D, F, device=dev(), generator=g) / math.sqrt(F))
-    ba, bb = torch.randn(F, device=dev(), generator=g), torch.randn(D, device=dev(), generator=g)
-    R = bf(torch.randn(M, D, device=dev(), generator=g)); G = bf(torch.randn(M, F, device=dev(), generator=g))
-    d1, d2 = _drop(11, 2, 5, 0.1), _drop(11, 2, 6, 0.1)
-    cases = [
-        (dict(bias=ba, relu=1, drop=d1), dict(bias=bb, drop=d2, residual=R, ldr=D)),      # FFN forward, training
-        (dict(bias=ba, relu=1), dict(bias=bb, residual=R, ldr=D)),                         # FFN forward, eval
-        (dict(gate=G, ldg=F, gate_scale=1.0 / 0.9), dict(residual=R, ldr=D)),              # data-gradient chain
-        (dict(), dict()),
-    ]
-    for k1, k2 in cases:
-        e1, e2 = _epi(N, **k1), _epi(N, **k2)
-        H = torch.empty(M, F, dtype=torch.bfloat16, device=dev()); Y = torch.empty(M, D, dtype=torch.bfloat16, device=dev())
-        N.check(L.iq_gemm_bf16_chain(X.data_ptr(), D, Wa.data_ptr(), D, H.data_ptr(), F, Wb.data_ptr(), F, Y.data_ptr(), D,
-                                     M, F, D, C.byref(e1), C.byref(e2), stream()), "chain")
-        H2 = run_gemm(L, X, Wa, M, F, D, **k1)
-        Y2 = run_gemm(L, H2, Wb, M, D, F, **k2)
-        assert torch.equal(H, H2), f"H differs ({list(k1)})"
-        if "bias" in k2 or not k2:
-            assert torch.equal(Y, Y2), f"Y differs ({list(k2)})"
-        else:   # residual only: the separate GEMM streams R as K stages (last add inside the MFMA): rounding ties may differ
-            dy = (Y.float() - Y2.float()).abs()
-            assert (dy > 0).float().mean().item() < 1e-4 and (dy <= 2.0 ** -7 * Y2.float().abs() + 1e-6).all()
-    # and against fp64 for the plain case
-    ref = (X.double() @ Wa.double().t()).to(torch.bfloat16).double() @ Wb.double().t()
-    close_bf16(Y, ref, "chain vs fp64")
+    X1 = bf(torch.randn(M, D, device=dev(), generator=g))
+    W1 = bf(torch.randn(F, D, device=dev(), generator=g) / math.sqrt(D))
+    W2 = bf(torch.randn(D, F, device=dev(), generator=g) / math.sqrt(F))
+    b1, b2 = torch.randn(F, device=dev(), generator=g), torch.randn(D, device=dev(), generator=g)
+    gamma = torch.rand(D, device=dev(), generator=g) + 0.5
+    beta = torch.randn(D, device=dev(), generator=g)
+    d1, d2 = _drop(77, 3, 5, pdrop), _drop(77, 3, 6, pdrop)
+    # two launches
+    H0 = run_gemm(L, X1, W1, M, F, D, bias=b1, relu=1, drop=d1) if pdrop > 0 else run_gemm(L, X1, W1, M, F, D, bias=b1, relu=1)
+    Z0 = torch.empty(M, D, dtype=torch.bfloat16, device=dev()); X0 = torch.empty_like(Z0)
+    mean0 = torch.empty(M, device=dev()); rstd0 = torch.empty(M, device=dev())
+    N.check(L.iq_gemm_bf16_ln(H0.data_ptr(), F, W2.data_ptr(), F, b2.data_ptr(), X1.data_ptr(), D, C.byref(d2) if pdrop > 0 else None,
+                              gamma.data_ptr(), beta.data_ptr(), 1e-12, Z0.data_ptr(), X0.data_ptr(), mean0.data_ptr(),
+                              rstd0.data_ptr(), M, D, F, stream()), "gemm_ln")
+    # one launch
+    nan = float("nan")
+    H1 = torch.full((M, F), nan, dtype=torch.bfloat16, device=dev())
+    Z1 = torch.full((M, D), nan, dtype=torch.bfloat16, device=dev()); X2 = torch.full((M, D), nan, dtype=torch.bfloat16, device=dev())
+    mean1 = torch.full((M,), nan, device=dev()); rstd1 = torch.full((M,), nan, device=dev())
+    N.check(L.iq_ffn_chain_fwd(X1.data_ptr(), W1.data_ptr(), b1.data_ptr(), C.byref(d1) if pdrop > 0 else None, H1.data_ptr(),
+                               W2.data_ptr(), b2.data_ptr(), C.byref(d2) if pdrop > 0 else None, gamma.data_ptr(), beta.data_ptr(),
+                               1e-12, Z1.data_ptr(), X2.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), frames, S, D, F, stream()),
+            "ffn_chain")
+    def ties_only(a, b, what, frac, abs_=1e-5):
+        ne = a.view(torch.int16) != b.view(torch.int16)
+        assert ne.float().mean().item() <= frac, f"{what}: {ne.float().mean().item():.3g} of the elements differ"
+        # one bf16 ulp of the larger value, or -- next to a ReLU zero -- an fp32 rounding of the pre-activation
+        excess = (a.float() - b.float()).abs() - (torch.maximum(a.float().abs(), b.float().abs()) * 2 ** -7 + abs_)
+        assert excess.max().item() <= 0.0, f"{what}: more than one bf16 ulp apart ({excess.max().item():.3g})"
+    assert ((H0 == 0) != (H1 == 0)).float().mean().item() <= 1e-4, "ReLU / dropout pattern of H differs from the FFN1 launch"
+    ties_only(H0, H1, "H", 2e-4)
+    # Z: a one-ulp difference of an H element (|h| ~ 1-4) moves the 192 sums it enters by ~|h| 2^-8 |w2| ~ 1e-3: beside ties,
+    # elements with |z| << 1 may land two or three of their own (small) ulps apart
+    ties_only(Z0, Z1, "Z", 2e-3, abs_=4e-3)
+    same = (Z0.view(torch.int16) == Z1.view(torch.int16)).all(1)            # rows whose Z agrees bit for bit
+    assert same.float().mean().item() > 0.7
+    assert torch.allclose(mean0[same], mean1[same], rtol=0, atol=2e-6 * (mean0.abs().max().item() + 1))
+    assert torch.allclose(rstd0[same], rstd1[same], rtol=2e-6, atol=0)
+    ulp = (X0.float() - X2.float()).abs()[same] / (X0.float().abs()[same] * 2 ** -7 + 1e-6)
+    assert ulp.max().item() <= 1.0 + 1e-3, ulp.max().item()
+    if pdrop > 0:
+        kept = (H1.float() != 0).float().mean().item() / max((run_gemm(L, X1, W1, M, F, D, bias=b1, relu=1).float() != 0).float().mean().item(), 1e-9)
+        assert abs(kept - (1 - pdrop)) < 0.02, kept
+    else:
+        h = torch.relu(X1.double() @ W1.double().t() + b1.double()).to(torch.bfloat16).double()
+        zf = h @ W2.double().t() + b2.double() + X1.double()
+        close_bf16(Z1, zf, "Z vs fp64")
+        zb = Z1.double()
+        mu = zb.mean(-1, keepdim=True); var = zb.var(-1, unbiased=False, keepdim=True)
+        close_bf16(X2, gamma.double() * ((zb - mu) / torch.sqrt(var + 1e-12)) + beta.double(), "X vs fp64")
 
 
 @pytest.mark.parametrize("M,K,N_", [(5000, 768, 192), (130, 576, 192), (50432, 768, 192), (999, 384, 192), (4000, 1024, 128),

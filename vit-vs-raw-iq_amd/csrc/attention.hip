@@ -189,52 +189,72 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16* __res
         __syncthreads();
       }
       if (active) {
+        // wave-uniform trims (S = 197: 224 padded rows): the second 16 queries of the last tile and the second 16 keys of
+        // the last block can be pure padding -- their products and softmax work are skipped; the key < S select runs only
+        // in the one block that holds padding keys
+        const bool u1 = qt * 32 + 16 < S;
         for (int kb = 0; kb < krows; kb += 32) {
+          const bool k1 = k0 + kb + 16 < S;
+          const bool kpad = k0 + kb + 32 > S;
           f32x4 sc[2][2];
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt) {
+            if (kt == 1 && !k1) {
+              sc[0][1] = f32x4{0.f, 0.f, 0.f, 0.f}; sc[1][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+              continue;
+            }
             bf16x8 kf[C::KS];
 #pragma unroll
             for (int s = 0; s < C::KS; ++s) kf[s] = row_frag_lds<DH>(Ks, kb + kt * 16 + c16, s, lane);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
               f32x4 a = {0.f, 0.f, 0.f, 0.f};
+              if (u == 0 || u1) {
 #pragma unroll
-              for (int s = 0; s < C::KS; ++s) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[s], qf[u][s], a, 0, 0, 0);
+                for (int s = 0; s < C::KS; ++s) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[s], qf[u][s], a, 0, 0, 0);
+              }
               sc[u][kt] = a;
             }
           }
           bf16x8 pb[2];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !u1) { pb[1] = bf16x8{}; continue; }
             float mx = NEG_BIG;
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt) {
+              if (kt == 1 && !k1) continue;
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const int key = k0 + kb + kt * 16 + 4 * g + r;
                 float x = sc[u][kt][r];               // raw score: the positive scale commutes with max and is folded
                 if (MASKED) {
+                  const int key = k0 + kb + kt * 16 + 4 * g + r;
                   const int q = qt * 32 + u * 16 + c16;
                   if (key < S && q < S && !mk[(long)q * S + key]) x = masked_raw;
                 }
-                x = key < S ? x : NEG_BIG;            // into the exp2 argument below (one fma instead of mul + sub)
+                if (kpad) {                           // into the exp2 argument below (one fma instead of mul + sub)
+                  const int key = k0 + kb + kt * 16 + 4 * g + r;
+                  x = key < S ? x : NEG_BIG;
+                }
                 sc[u][kt][r] = x;
                 mx = fmaxf(mx, x);
               }
+            }
             mx = group4_max(mx) * scale_log2;         // running max m[u] lives in the scaled (log2) domain
             const float mn = fmaxf(m[u], mx);
             const float alpha = fast_exp2(m[u] - mn);
             m[u] = mn;
             float rs = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt) {
+              if (kt == 1 && !k1) continue;
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const float pv = fast_exp2(fmaf(sc[u][kt][r], scale_log2, -mn));
                 sc[u][kt][r] = pv;
                 rs += pv;
               }
+            }
             lsum[u] = lsum[u] * alpha + rs;
 #pragma unroll
             for (int dt = 0; dt < C::DT; ++dt) o[u][dt] *= alpha;
@@ -243,8 +263,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const bf16* __res
 #pragma unroll
           for (int dt = 0; dt < C::DT; ++dt) {
             const bf16x8 vt = tr_frag(Vs, C::LD, kb, dt * 16, lane);
-#pragma unroll
-            for (int u = 0; u < 2; ++u) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pb[u], o[u][dt], 0, 0, 0);
+            o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pb[0], o[0][dt], 0, 0, 0);
+            if (u1) o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pb[1], o[1][dt], 0, 0, 0);
           }
         }
       }
@@ -357,9 +377,11 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const bf16* __
       }
       if (!have) continue;
       for (int ql = 0; ql < rows; ql += 32) {
+        const bool u1 = q0 + ql + 16 < S;      // wave-uniform: the block's second 16 queries are not all padding
         f32x4 p[2], ds[2];   // [u]
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
+          if (u == 1 && !u1) { p[1] = f32x4{0.f, 0.f, 0.f, 0.f}; ds[1] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
           f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int s = 0; s < C::KS; ++s) {
@@ -450,11 +472,14 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const bf16* __
         __syncthreads();
       }
       if (!have) continue;
+      const bool u1 = qblk * 32 + 16 < S;               // wave-uniform: this block's second 16 queries are not all padding
       for (int kl = 0; kl < rows; kl += 32) {
         const bool kblk_partial = k0 + kl + 32 > S;     // wave-uniform
+        const bool k1 = k0 + kl + 16 < S;               // the block's second 16 keys are not all padding
         f32x4 ds[2][2];  // [u][kt]
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
+          if (kt == 1 && !k1) { ds[0][1] = f32x4{0.f, 0.f, 0.f, 0.f}; ds[1][1] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
           bf16x8 ka[C::KS], va[C::KS];
 #pragma unroll
           for (int s = 0; s < C::KS; ++s) {
@@ -463,6 +488,7 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const bf16* __
           }
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !u1) { ds[1][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
             f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < C::KS; ++s) {
@@ -489,8 +515,8 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attn_bwd_kernel(const bf16* __
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
           const bf16x8 kT = tr_frag(I0, C::LD, kl, dt * 16, lane);
-#pragma unroll
-          for (int u = 0; u < 2; ++u) dq[dt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, dsB[u], dq[dt][u], 0, 0, 0);
+          dq[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, dsB[0], dq[dt][0], 0, 0, 0);
+          if (u1) dq[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, dsB[1], dq[dt][1], 0, 0, 0);
         }
       }
     }

@@ -1,0 +1,404 @@
+// The position-wise feed-forward sub-layer + norm2 in ONE launch, the hidden activation never re-read (gfx950):
+//
+//     H[M,F]  = dropout1(relu(X1[M,D] * W1[F,D]^T + b1))                      bf16, written once (backward reads it)
+//     Z[M,D]  = dropout2(H * W2[D,F]^T + b2) + X1                              bf16 (kept for backward)
+//     X[M,D]  = gamma * (Z - mean) * rstd + beta ; mean, rstd fp32 [M]         (norm2, eps inside the square root)
+//
+// = PositionwiseFeedForward.forward (V/models/layers/position_wise_feed_forward.py:12-17: Linear, ReLU, Dropout, Linear)
+// followed by `x = norm2(dropout2(ffn(x)) + x)` of EncoderLayer.forward (V/models/blocks/encoder_layer.py:30-33).
+//
+// Run as two launches (FFN1 GEMM, then FFN2 GEMM + LayerNorm) the hidden activation H -- 4x the width of every other
+// activation -- is written to HBM and read straight back (cfg B: 77.5 MB each way per layer), and each launch pays its own
+// pipeline fill and drain.  Here the ROWS are stationary and the WEIGHTS stream:
+//   * a wave owns 32 consecutive rows (two 16-row groups) for the whole kernel.  Its X1 rows sit in registers as MFMA
+//     fragments (loaded once, fragment-shaped, straight from global memory), its Z accumulators (32 rows x D, fp32) too;
+//   * the hidden dimension is walked in chunks of 64 units.  Per chunk: acc1 = X1 W1_c^T (K = D), epilogue (bias, ReLU,
+//     Philox dropout, round to bf16, 16-byte store of H) -- and the eight bf16 values a lane has just packed ARE its
+//     activation fragment of the second product (an accumulator tile as the next MFMA's operand: the k-slot order inside an
+//     MFMA is free as long as both operands agree, so lane group g carries hidden units {0,16,8,24}[g] .. +7 of a 32-unit
+//     step and the W2 fragment is read with the same permutation): acc2 += H_c W2_c^T without H touching LDS or HBM again;
+//   * LDS holds nothing but the weight ring: chunk c's W1 rows [64 x D] and W2 columns [D x 64] (24.6 KB each at D = 192)
+//     arrive by global_load_lds two chunks ahead (3 slots); on the source side the 16-byte chunks of a row are put in
+//     lane-group order (the {0,16,8,24} permutation) and XOR-swizzled, so that the fragment reads (ds_read_b128, 16 rows x
+//     the consecutive chunks of two lane groups) are bank-conflict free.  Every CU streams the layer's 0.6 MB of
+//     FFN weights from L2 once per 224 rows.  One workgroup barrier per chunk (ring hand-over), none for the data path;
+//   * tail: z = dropout2(acc2 + b2) + x1 with x1 taken from the X1 fragments (the same column permutation makes them exactly
+//     the 8 columns a lane owns after the tail's permlane swap), LayerNorm statistics two-pass on the bf16-rounded z by lane
+//     sums + two shuffles (a wave owns whole rows), Z / X / statistics stored from registers.
+// K order of both products is the plain ascending one (chunks, then 32-unit steps): H and Z are bit-identical to
+// iq_gemm_bf16_nt + iq_gemm_bf16_ln.  First version of this file (round 3, measured, replaced; kept as
+// scripts/dbg/variants/ffn_chain_v1_frame_images.hip): one workgroup per frame with X1 and H_c as LDS images and weight
+// fragments loaded from L2 into registers 1-2 k-steps ahead: 79 us for cfg B's layer against 38 + 37 for the two launches --
+// every k-step exposed an L2 round trip, and registers left no room to look further ahead.  A ring in LDS costs no registers.
+#include <stdlib.h>
+
+#include "common.h"
+#include "iqvit.h"
+#include "prof.h"
+
+namespace {
+
+constexpr int FC_CHUNK = 64, FC_NS = 3, FC_MAXW = 7;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
+
+struct FfnChainParams {
+  const bf16* X1; const bf16* W1; const bf16* W2;      // [M,D], [F,D], [D,F]
+  const float* b1; const float* b2; const float* gamma; const float* beta;
+  bf16* H; bf16* Z; bf16* X; float* mean; float* rstd;  // [M,F], [M,D], [M,D], [M], [M]
+  int M, F;
+  float eps;
+  int drop1_on, drop2_on; IqRng rng1, rng2; uint32_t thresh1, thresh2; float dscale1, dscale2;
+};
+
+// W1 image rows are D * 2 bytes (24 | 16 chunks of 16 B), W2 image rows 128 B (8 chunks).  Swizzles (involutions on the chunk
+// index) that put the 16 rows x {k-chunk a, b} of a ds_read_b128 lane group on 16 distinct 16-byte slots of the 256-byte bank row:
+//   384 B rows (24 = 8 mod 16: the row's parity already moves the slot by 8): low 3 bits ^= (row >> 1) & 7
+//   256 B rows: chunk ^= row & 15          128 B rows: chunk ^= (row >> 1) & 7
+template <int CPR> __device__ __forceinline__ int fc_swz(int row, int ch) {
+  return CPR == 16 ? (ch ^ (row & 15)) : CPR == 8 ? (ch ^ ((row >> 1) & 7)) : ((ch & ~7) | ((ch & 7) ^ ((row >> 1) & 7)));
+}
+// hidden-unit / column offset (in units of 8) of lane group g inside a 32-wide k-step: {0, 16, 8, 24} / 8
+__device__ __forceinline__ int fc_kperm(int g) { return ((g & 1) << 1) | (g >> 1); }
+
+// NW = waves per workgroup (compile time: the ring's counted waits need the number of DMA pieces per wave), DROP1 = dropout
+// on the hidden activation (its Philox rounds are the kernel's largest block of vector work; computing a chunk's keep flags
+// one chunk ahead, beside the second product's MFMAs, measured slower: 71.8 vs 65.9 us).
+template <int D, int NW, bool DROP1>
+__global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChainParams p) {
+  constexpr int XCPR = D / 8;                           // 16-byte chunks per W1 image row
+  constexpr int KS1 = D / 32;                           // k-steps of the first product: 6 | 4
+  constexpr int NT2 = D / 16, NP2 = NT2 / 2;            // output column tiles / pairs: 12, 6 | 8, 4
+  constexpr int W1_BYTES = FC_CHUNK * D * 2, W2_BYTES = D * FC_CHUNK * 2, SLOT = W1_BYTES + W2_BYTES;
+  constexpr int W1_PIECES = W1_BYTES / 1024, PIECES = SLOT / 1024;     // 1 KiB DMA pieces per chunk: 48 | 32
+  constexpr int PPW = (PIECES + NW - 1) / NW;                          // per wave (a wave past the end repeats the last piece)
+  static_assert(PPW + 8 < 64, "counted vmcnt");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int nwave = NW;
+  const int g = lane >> 4, c16 = lane & 15;
+  const bool odd = (g & 1) != 0;
+  const int F = p.F;
+  const int nchunk = F / FC_CHUNK;
+  const long row0 = ((long)blockIdx.x * nwave + wave) * 32;      // this wave's first row
+  const bool have = row0 < p.M;                                   // wave-uniform (a trailing wave may own no rows: it still feeds the ring)
+
+  // ---- weight ring: this wave's PPW pieces of every chunk; per-lane source offsets are chunk-invariant ------------------------
+  // image position (row r, slot s) holds "slot-order" chunk q = swz(r, s), i.e. the k-chunk lane group (q & 3) reads in
+  // k-step (q >> 2): natural chunk 4 (q >> 2) + kperm(q & 3)
+  unsigned poff[PPW];                                   // bytes from W1 + f0 * D (W1 pieces) or W2 + f0 (W2 pieces)
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int pc = min(wave + i * NW, PIECES - 1);
+    const int lin = pc * 64 + lane;
+    if (pc < W1_PIECES) {                               // W1 rows f0 .. f0 + 63, all D columns
+      const int r = lin / XCPR, sl = lin - r * XCPR;
+      const int q = fc_swz<XCPR>(r, sl);
+      poff[i] = (unsigned)((r * D + ((q & ~3) | fc_kperm(q & 3)) * 8) * 2);
+    } else {                                            // W2 rows 0 .. D - 1, columns f0 .. f0 + 63
+      const int l2 = lin - W1_PIECES * 64;
+      const int r = l2 >> 3, sl = l2 & 7;
+      const int q = fc_swz<8>(r, sl);
+      poff[i] = (unsigned)((r * F + ((q & ~3) | fc_kperm(q & 3)) * 8) * 2);
+    }
+  }
+  auto issue_chunk = [&](int c) {
+    unsigned char* slot = smem + (c % FC_NS) * SLOT;
+    const char* base1 = reinterpret_cast<const char*>(p.W1 + (long)c * FC_CHUNK * D);
+    const char* base2 = reinterpret_cast<const char*>(p.W2 + (long)c * FC_CHUNK);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = min(wave + i * NW, PIECES - 1);    // wave-uniform
+      const char* base = pc < W1_PIECES ? base1 : base2;
+      __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(base + poff[i]), (lds_void_t*)(slot + pc * 1024), 16, 0, 0);
+    }
+  };
+  issue_chunk(0);
+  if (nchunk > 1) issue_chunk(1);
+
+  // ---- this wave's X1 rows as activation fragments: xf[rg][ks] = row 16 rg + c16, columns 32 ks + 8 kperm(g) .. +7 ----------
+  bf16x8 xf[2][KS1];
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg) {
+    const long r = min(row0 + rg * 16 + c16, (long)p.M - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks)
+      xf[rg][ks] = have ? *reinterpret_cast<const bf16x8*>(p.X1 + r * D + 32 * ks + 8 * fc_kperm(g)) : bf16x8{};
+  }
+  const IqRng rng1 = DROP1 ? rng_resolve(p.rng1) : p.rng1;
+  const IqRng rng2 = p.drop2_on ? rng_resolve(p.rng2) : p.rng2;
+  // b1 lives in LDS behind the ring: a register-destination global load inside the chunk loop makes hipcc wait vmcnt(0) at
+  // its first use (cdna_hip_programming.md, "mixing load kinds in one k-loop"), i.e. for the ring pieces just requested
+  float* b1s = reinterpret_cast<float*>(smem + FC_NS * SLOT);
+  for (int i = tid; i < F / 4; i += NW * 64) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
+  // Everything requested so far has landed (chunks 0 and 1 as well: they had the X1 round trip to travel); the X1 fragments
+  // are then passed through an empty asm so that the compiler stops tracking them as results of pending loads -- it cannot
+  // see across the loop's back edge and would otherwise wait vmcnt(0) before their first use in EVERY iteration.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) asm volatile("" : "+v"(xf[rg][ks]));
+
+  f32x4 acc2[2][NT2];
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+    for (int j = 0; j < NT2; ++j) acc2[rg][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // a wave whose 32 rows all exist stores exactly 4 H vectors per chunk: its ring waits can be COUNTED (the stores and the
+  // next chunk's pieces stay in flight); a ragged wave waits for everything
+  const bool full = row0 + 32 <= p.M;
+  for (int c = 0; c < nchunk; ++c) {
+    // chunk c has landed for this wave (counted: the chunk requested one iteration ago and the H stores of the last two
+    // iterations may still be in flight); the barrier makes that true for every wave and says slot (c+2) % 3 = (c-1) % 3 is
+    // no longer read
+#ifdef FC_NO_RING      // ablation build (timing only): no ring hand-over after the prologue
+    if (c > 0) goto ring_done;
+#endif
+    if (c == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (b1 image written; the ring's first chunks: above)
+    else if (!full || nchunk < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (c + 1 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW + 8) : "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (c + 2 < nchunk) issue_chunk(c + 2);
+#ifdef FC_NO_RING
+  ring_done:
+#endif
+    if (!have) continue;
+    const unsigned char* W1s = smem + (c % FC_NS) * SLOT;
+    const unsigned char* W2s = W1s + W1_BYTES;
+    const int f0 = c * FC_CHUNK;
+    // ---- first product: acc1[rg][t] = X1 rows x hidden units f0 + 16 t .. +15 -------------------------------------------------
+    f32x4 acc1[2][4];
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc1[rg][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // weight fragments of k-step ks + 1 are read (4 x ds_read_b128) before the 8 MFMAs of k-step ks are issued: left to
+    // itself the compiler read two fragments at a time and drained lgkmcnt before every four MFMAs
+    bf16x8 wq[2][4];
+    auto read_w1 = [&](int ks, bf16x8 (&dst)[4]) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = 16 * t + c16;
+        dst[t] = *reinterpret_cast<const bf16x8*>(W1s + r * (D * 2) + fc_swz<XCPR>(r, 4 * ks + g) * 16);
+      }
+    };
+    read_w1(0, wq[0]);
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+      if (ks + 1 < KS1) read_w1(ks + 1, wq[(ks + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#ifdef FC_NO_MFMA      // ablation build (timing only)
+        asm volatile("" :: "v"(wq[ks & 1][t]));
+#else
+        acc1[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ks & 1][t], xf[0][ks], acc1[0][t], 0, 0, 0);
+        acc1[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ks & 1][t], xf[1][ks], acc1[1][t], 0, 0, 0);
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- epilogue of the first product; the packed values are the second product's activation fragments ----------------------
+    bf16x8 hf[2][2];                                    // [rg][k-step of the chunk]
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      const int col = f0 + 32 * jp + (odd ? 16 + 4 * (g - 1) : 4 * g);       // first of this lane's 8 hidden units
+      const f32x4 b_lo = *reinterpret_cast<const f32x4*>(b1s + col), b_hi = *reinterpret_cast<const f32x4*>(b1s + col + 4);
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg) {
+        float w[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float va = acc1[rg][2 * jp][r], vb = acc1[rg][2 * jp + 1][r];
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
+          w[r] = fmaxf(__uint_as_float(sw[0]) + b_lo[r], 0.f);
+          w[4 + r] = fmaxf(__uint_as_float(sw[1]) + b_hi[r], 0.f);
+        }
+        const long grow = row0 + rg * 16 + c16;
+        if (DROP1) {
+          const uint32_t keep = dropout_keep8(rng1, (uint64_t)(grow * F + col) >> 3, p.thresh1);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = ((keep >> e) & 1u) ? w[e] * p.dscale1 : 0.f;
+        }
+        hf[rg][jp] = pack8(w);
+#ifndef FC_NO_HSTORE    // (ablation build, timing only, leaves H unwritten)
+        if (grow < p.M) *reinterpret_cast<bf16x8*>(p.H + grow * F + col) = hf[rg][jp];
+#endif
+      }
+    }
+    // ---- second product: acc2[rg][j] += H_c x W2 rows 16 j .. +15, hidden units f0 .. f0 + 63 ----------------------------------
+    // (same read-ahead: groups of four output tiles; group q = k-step q / NG4, tiles 4 (q % NG4) .. + 3)
+    constexpr int NG4 = NT2 / 4, NGRP = 2 * NG4;        // 3 | 2 groups per k-step, 6 | 4 per chunk
+    auto read_w2 = [&](int q, bf16x8 (&dst)[4]) {
+      const int jp = q / NG4, j0 = 4 * (q % NG4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = 16 * (j0 + t) + c16;
+        dst[t] = *reinterpret_cast<const bf16x8*>(W2s + r * 128 + fc_swz<8>(r, 4 * jp + g) * 16);
+      }
+    };
+    read_w2(0, wq[0]);
+#pragma unroll
+    for (int q = 0; q < NGRP; ++q) {
+      if (q + 1 < NGRP) read_w2(q + 1, wq[(q + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int jp = q / NG4, j0 = 4 * (q % NG4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#ifdef FC_NO_MFMA
+        asm volatile("" :: "v"(wq[q & 1][t]), "v"(hf[0][jp]), "v"(hf[1][jp]));
+#else
+        acc2[0][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 1][t], hf[0][jp], acc2[0][j0 + t], 0, 0, 0);
+        acc2[1][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 1][t], hf[1][jp], acc2[1][j0 + t], 0, 0, 0);
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (!have) return;
+
+  // ---- tail: z = dropout2(acc2 + b2) + x1 (bf16), LayerNorm over the wave's own rows -----------------------------------------
+  // pair jp covers columns 32 jp .. 32 jp + 31; after the swap this lane holds columns 32 jp + 8 kperm(g) .. +7 -- exactly xf[rg][jp]
+  const float invD = 1.0f / (float)D;
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg) {
+    const long grow = row0 + rg * 16 + c16;
+    float z[NP2][8];
+    float s1 = 0.f;
+#pragma unroll
+    for (int jp = 0; jp < NP2; ++jp) {
+      const int col = 32 * jp + (odd ? 16 + 4 * (g - 1) : 4 * g);
+      const f32x4 b_lo = *reinterpret_cast<const f32x4*>(p.b2 + col), b_hi = *reinterpret_cast<const f32x4*>(p.b2 + col + 4);
+      float w[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float va = acc2[rg][2 * jp][r], vb = acc2[rg][2 * jp + 1][r];
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
+        w[r] = __uint_as_float(sw[0]) + b_lo[r];
+        w[4 + r] = __uint_as_float(sw[1]) + b_hi[r];
+      }
+      if (p.drop2_on) {
+        const uint32_t keep = dropout_keep8(rng2, (uint64_t)(grow * D + col) >> 3, p.thresh2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = ((keep >> e) & 1u) ? w[e] * p.dscale2 : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w[e] += (float)xf[rg][jp][e];
+      const bf16x8 zb = pack8(w);
+      if (grow < p.M) *reinterpret_cast<bf16x8*>(p.Z + grow * D + col) = zb;
+      unpack8(zb, z[jp]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s1 += z[jp][e];
+    }
+    s1 += __shfl_xor(s1, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    const float mean = s1 * invD;
+    float s2 = 0.f;
+#pragma unroll
+    for (int jp = 0; jp < NP2; ++jp)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = z[jp][e] - mean; s2 += d * d; }
+    s2 += __shfl_xor(s2, 16, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float rstd = 1.0f / sqrtf(s2 * invD + p.eps);
+    if (grow < p.M) {
+      if (g == 0) { p.mean[grow] = mean; p.rstd[grow] = rstd; }
+#pragma unroll
+      for (int jp = 0; jp < NP2; ++jp) {
+        const int col = 32 * jp + (odd ? 16 + 4 * (g - 1) : 4 * g);
+        const f32x4 g_lo = *reinterpret_cast<const f32x4*>(p.gamma + col), g_hi = *reinterpret_cast<const f32x4*>(p.gamma + col + 4);
+        const f32x4 e_lo = *reinterpret_cast<const f32x4*>(p.beta + col), e_hi = *reinterpret_cast<const f32x4*>(p.beta + col + 4);
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          y[e] = g_lo[e] * ((z[jp][e] - mean) * rstd) + e_lo[e];
+          y[4 + e] = g_hi[e] * ((z[jp][4 + e] - mean) * rstd) + e_hi[e];
+        }
+        *reinterpret_cast<bf16x8*>(p.X + grow * D + col) = pack8(y);
+      }
+    }
+  }
+}
+
+// waves per workgroup: 32 rows each; one workgroup per CU (the ring is most of a CU's LDS), so as many waves as it takes to
+// cover M with <= 256 workgroups -- of the instantiated counts {2, 4, 7}
+inline int chain_waves(int M) {
+  const long units = ((long)M + 31) / 32;
+  const long nw = (units + 255) / 256;
+  return nw <= 2 ? 2 : nw <= 4 ? 4 : FC_MAXW;
+}
+
+template <int D, int NW>
+int launch_chain(const FfnChainParams& p, hipStream_t st) {
+  constexpr int SLOT = 2 * FC_CHUNK * D * 2;
+  const size_t lds = (size_t)FC_NS * SLOT + (size_t)p.F * sizeof(float);     // ring (147,456 | 98,304 B) + b1
+  const long units = ((long)p.M + 31) / 32;
+  const int grid = (int)((units + NW - 1) / NW);
+#define FC_LAUNCH(DROP_)                                                                                                      \
+  do {                                                                                                                        \
+    auto k = ffn_chain_fwd_kernel<D, NW, DROP_>;                                                                              \
+    static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    (void)attr;                                                                                                               \
+    k<<<grid, NW * 64, lds, st>>>(p);                                                                                         \
+  } while (0)
+  if (p.drop1_on) FC_LAUNCH(true);
+  else FC_LAUNCH(false);
+#undef FC_LAUNCH
+  return iq_launch_status();
+}
+template <int D>
+int launch_chain_d(const FfnChainParams& p, hipStream_t st) {
+  switch (chain_waves(p.M)) {
+    case 2: return launch_chain<D, 2>(p, st);
+    case 4: return launch_chain<D, 4>(p, st);
+    default: return launch_chain<D, FC_MAXW>(p, st);
+  }
+}
+
+}  // namespace
+
+// D = 128 | 192, F a multiple of 64 (S: rows per frame -- any; rows are owned by waves, 32 at a time, regardless of frames)
+extern "C" int iq_ffn_chain_supported(int S, int D, int F) {
+  if (!(D == 128 || D == 192) || F < FC_CHUNK || (F % FC_CHUNK) || S <= 0) return 0;
+  return (size_t)FC_NS * 2 * FC_CHUNK * D * 2 + (size_t)F * sizeof(float) <= (size_t)160 * 1024 ? 1 : 0;      // F <= 4096 at D = 192
+}
+
+extern "C" int iq_ffn_chain_fwd(const void* X1, const void* W1, const float* b1, const iq_dropout_t* drop1, void* H,
+                                const void* W2, const float* b2, const iq_dropout_t* drop2, const float* gamma,
+                                const float* beta, float eps, void* Z, void* X, float* mean, float* rstd, int frames, int S,
+                                int D, int F, iq_stream_t stream) {
+  if (frames <= 0) return IQ_OK;
+  if (!X1 || !W1 || !b1 || !H || !W2 || !b2 || !gamma || !beta || !Z || !X || !mean || !rstd) return IQ_ERR_ARG;
+  if (!iq_ffn_chain_supported(S, D, F)) return IQ_ERR_UNSUPPORTED;
+  if (((uintptr_t)X1 | (uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)H | (uintptr_t)Z | (uintptr_t)X | (uintptr_t)b1 | (uintptr_t)b2 |
+       (uintptr_t)gamma | (uintptr_t)beta) % 16) return IQ_ERR_ARG;
+  if ((long)frames * S > 0x7FFFFFFFL) return IQ_ERR_UNSUPPORTED;
+  FfnChainParams p = {};
+  p.X1 = (const bf16*)X1; p.W1 = (const bf16*)W1; p.W2 = (const bf16*)W2;
+  p.b1 = b1; p.b2 = b2; p.gamma = gamma; p.beta = beta;
+  p.H = (bf16*)H; p.Z = (bf16*)Z; p.X = (bf16*)X; p.mean = mean; p.rstd = rstd;
+  p.M = frames * S; p.F = F; p.eps = eps;
+  auto fill = [](const iq_dropout_t* d, int* on, IqRng* r, uint32_t* th, float* sc) -> bool {
+    *on = 0; *th = 0; *sc = 1.f; *r = IqRng{0, 0, 0, nullptr};
+    if (d && d->p > 0.f) {
+      if (d->p >= 1.f) return false;
+      *on = 1;
+      r->seed = d->seed; r->step = d->step; r->site = d->site; r->step_dev = d->step_dev;
+      *th = dropout_thresh(d->p);
+      *sc = dropout_scale(d->p);
+    }
+    return true;
+  };
+  if (!fill(drop1, &p.drop1_on, &p.rng1, &p.thresh1, &p.dscale1) || !fill(drop2, &p.drop2_on, &p.rng2, &p.thresh2, &p.dscale2))
+    return IQ_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  IQ_PROF(IQ_FAM_GEMM_NT, st);
+  const double M = (double)p.M;
+  IQ_PROF_K(2.0 * (M * D * 3 + M * F + 2.0 * D * F) + 8.0 * M, 4.0 * M * D * F, "ffn_chain_fwd_kernel<%d, %d, %s>", D, chain_waves(p.M), p.drop1_on ? "true" : "false");
+  return D == 192 ? launch_chain_d<192>(p, st) : launch_chain_d<128>(p, st);
+}

@@ -415,14 +415,17 @@ extern "C" int iq_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   // Column tile: 128 for wide N, else 64 (the register-staged fallback for K % 32 != 0 uses the same choice).
   const bool wide = (N % 128 == 0 || N > 512);
   const int bn = wide ? 128 : 64;
-  // Row tile: 128, or 64 when 128-row tiles would leave CUs idle (three workgroups fit a CU: fewer than 768 tiles is less
-  // than one full round).  cfg C (M = 16,640): the N = 128 data gradient is 130 tiles of 128 x 128, the QKV projection 390.
-  // The 64-row tile streams A once as well (the weight is re-read from L2).  IQ_TUNE_NT_ROWS = 64 | 128 forces it (probes).
+  // Row tile: 128, or 64 when the launch is only a round or two of 128-row tiles (three of them fit a CU: 768 slots): the
+  // last, partly filled round then costs a whole tile time.  cfg C (M = 16,640): FFN1 / gate data gradient = 1,040 tiles of
+  // 128 x 128 = 1.35 rounds, the QKV projection 390, the N = 128 data gradient 130.  The 64-row tile streams A once as well
+  // (the weight is re-read from L2).  cfg B's launches are 1,182..2,364 tiles and stay on 128 rows (64-row tiles measured
+  // slower there: more weight re-reads per byte of A).  IQ_TUNE_NT_ROWS = 64 | 128 forces the choice (probes).
   static const int tune_rows = [] { const char* e = getenv("IQ_TUNE_NT_ROWS"); return e ? atoi(e) : 0; }();
+  static const int tune_tiles = [] { const char* e = getenv("IQ_TUNE_NT_TILES"); return e ? atoi(e) : 512; }();
   int bm = BM;
   if (async_ok) {
     const long t128 = (long)((M + 127) / 128) * ((N + bn - 1) / bn);
-    if (tune_rows == 64 || (tune_rows == 0 && t128 < 512)) bm = 64;
+    if (tune_rows == 64 || (tune_rows == 0 && t128 < tune_tiles)) bm = 64;
   }
   p.tiles_m = (M + bm - 1) / bm;
   p.tiles_n = (N + bn - 1) / bn;

@@ -16,6 +16,7 @@
 //   every optimizer step), fp32 MFMA accumulation.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -239,6 +240,17 @@ WsPlan plan_ws(const iq_model* m, int B) {
 // M = 50432: D 192 K 192 22.4 vs 25.9 us, K 768 38.9 vs 46.0; D 128 K 128 16.3 vs 20.6, K 1024 31.4 vs 34.4; D 256 K 256 31.6 vs
 // 33.1 but K 1024 62.3 vs 55.7: its 64-row blocks re-stream the 512 KB weight twice as often).
 inline bool use_fused_ln(int D, int K) { return iq_gemm_ln_supported(D, K) && (D <= 192 || K <= 256); }
+
+// The feed-forward sub-layer of a frame in one workgroup (ffn_chain.hip).  IQ_TUNE_FFN_CHAIN=0|1 forces the choice (probes).
+// Measured (scripts/layer_kernels.py): cfg B (M = 50,432 rows, D 192, F 768) 60.9 us against 38.5 + 35.7 for the two launches;
+// cfg C (M = 16,640, D 128, F 1024) 42.5 against 18.9 + 19.2 -- with 32 rows per wave a small M leaves two or four waves per
+// CU, so the chain runs only where its workgroups are full (7 waves: M > 32,768 rows).
+inline bool use_ffn_chain(int M, int S, int D, int F) {
+  static const int tune = [] { const char* e = getenv("IQ_TUNE_FFN_CHAIN"); return e ? atoi(e) : -1; }();
+  if (!iq_ffn_chain_supported(S, D, F) || tune == 0) return false;
+  if (tune == 1) return true;
+  return M > 32768;
+}
 
 #define IQ_TRY(expr, what)                                                              \
   do {                                                                                  \
@@ -487,19 +499,27 @@ extern "C" int iq_model_forward(iq_model_t* m, const float* src, int batch, void
       IQ_TRY(iq_gemm_bf16_nt(ws + a.att, D, m->sh(o.wo), D, ws + a.z1, D, M, D, D, &e, stream), "out-proj GEMM");
       IQ_TRY(iq_ln_fwd(ws + a.z1, P + o.g1, P + o.be1, ws + a.x1, (float*)(ws + a.mean1), (float*)(ws + a.rstd1), M, D, 1e-12f, stream), "norm1");
     }
-    // ffn
-    memset(&e, 0, sizeof(e));
-    e.bias = P + o.b1; e.relu = 1; e.drop = site(m, seed, step_dev, 2 + 3 * l, tr);
-    IQ_TRY(iq_gemm_bf16_nt(ws + a.x1, D, m->sh(o.w1), D, ws + a.hid, F, M, F, D, &e, stream), "ffn1 GEMM");
+    // ffn + dropout2 + residual + norm2: one launch per layer where a frame's rows fit one workgroup (iq_ffn_chain_fwd: the
+    // hidden activation is consumed from LDS), else FFN1 then FFN2 (+ norm2 in its epilogue where a workgroup owns whole rows)
+    const iq_dropout_t drh = site(m, seed, step_dev, 2 + 3 * l, tr);
     const iq_dropout_t dr2 = site(m, seed, step_dev, 3 + 3 * l, tr);
-    if (use_fused_ln(D, F)) {
-      IQ_TRY(iq_gemm_bf16_ln(ws + a.hid, F, m->sh(o.w2), F, P + o.b2, ws + a.x1, D, &dr2, P + o.g2, P + o.be2, 1e-12f,
-                             ws + a.z2, ws + a.x2, (float*)(ws + a.mean2), (float*)(ws + a.rstd2), M, D, F, stream), "ffn2 GEMM + norm2");
+    if (use_ffn_chain(M, S, D, F)) {
+      IQ_TRY(iq_ffn_chain_fwd(ws + a.x1, m->sh(o.w1), P + o.b1, &drh, ws + a.hid, m->sh(o.w2), P + o.b2, &dr2, P + o.g2, P + o.be2,
+                              1e-12f, ws + a.z2, ws + a.x2, (float*)(ws + a.mean2), (float*)(ws + a.rstd2), B, S, D, F, stream),
+             "ffn chain + norm2");
     } else {
       memset(&e, 0, sizeof(e));
-      e.bias = P + o.b2; e.drop = dr2; e.residual = ws + a.x1; e.ldr = D;
-      IQ_TRY(iq_gemm_bf16_nt(ws + a.hid, F, m->sh(o.w2), F, ws + a.z2, D, M, D, F, &e, stream), "ffn2 GEMM");
-      IQ_TRY(iq_ln_fwd(ws + a.z2, P + o.g2, P + o.be2, ws + a.x2, (float*)(ws + a.mean2), (float*)(ws + a.rstd2), M, D, 1e-12f, stream), "norm2");
+      e.bias = P + o.b1; e.relu = 1; e.drop = drh;
+      IQ_TRY(iq_gemm_bf16_nt(ws + a.x1, D, m->sh(o.w1), D, ws + a.hid, F, M, F, D, &e, stream), "ffn1 GEMM");
+      if (use_fused_ln(D, F)) {
+        IQ_TRY(iq_gemm_bf16_ln(ws + a.hid, F, m->sh(o.w2), F, P + o.b2, ws + a.x1, D, &dr2, P + o.g2, P + o.be2, 1e-12f,
+                               ws + a.z2, ws + a.x2, (float*)(ws + a.mean2), (float*)(ws + a.rstd2), M, D, F, stream), "ffn2 GEMM + norm2");
+      } else {
+        memset(&e, 0, sizeof(e));
+        e.bias = P + o.b2; e.drop = dr2; e.residual = ws + a.x1; e.ldr = D;
+        IQ_TRY(iq_gemm_bf16_nt(ws + a.hid, F, m->sh(o.w2), F, ws + a.z2, D, M, D, F, &e, stream), "ffn2 GEMM");
+        IQ_TRY(iq_ln_fwd(ws + a.z2, P + o.g2, P + o.be2, ws + a.x2, (float*)(ws + a.mean2), (float*)(ws + a.rstd2), M, D, 1e-12f, stream), "norm2");
+      }
     }
     x = ws + a.x2;
   }
