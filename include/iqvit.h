@@ -118,10 +118,26 @@ int iq_gemm_bf16_lnbwd(const void* A, int lda, const void* Wt, int ldw, const vo
  * (V/models/blocks/encoder_layer.py:30-33).  H is consumed from LDS, never re-read from HBM.  H and Z are bit-identical to
  * iq_gemm_bf16_nt (bias, relu, drop1) followed by iq_gemm_bf16_ln; dropout indices as there (output element row*N + n).
  * W1 [F, D], W2 [D, F] bf16 row-major; all pointers 16-byte aligned. */
+/* iq_ffn_chain_bwd: the data path of the same sub-layer's backward in one launch (replaces the gate data-gradient GEMM and
+ * iq_gemm_bf16_lnbwd; autograd of position_wise_feed_forward.py:12-17 and of the norm1 feeding it, encoder_layer.py:24-25):
+ *   gH = (H > 0) ? (dO * W2t^T) * gate_scale : 0         bf16 [M,F]   (written once: the W1 / W2 weight gradients read it)
+ *        "H > 0" (ReLU and dropout1 of the forward pass at once) comes as ONE BIT per hidden unit in `gate_bits`,
+ *        iq_ffn_chain_gate_bytes(M, F) bytes written by iq_ffn_chain_fwd (its `gate_bits` argument, NULL = not wanted) in the
+ *        backward kernel's own wave / chunk / lane order (an opaque buffer between the two calls)
+ *   dX1 = gH * W1t^T + residual (rounded to bf16), then exactly iq_ln_bwd on it with z1 / mean / rstd / gamma:
+ *   dz bf16 [M,D], dy = dropout_mask(dz) * scale (only when drop->p > 0), partial: iq_ffn_chain_bwd_partial_rows(M) rows of
+ *   [2*D] fp32 (dgamma | dbeta partial sums, one row per 32 data rows) for the fused fixed-order reduction (iq_reduce_seg_t).
+ * W2t [F, D] and W1t [D, F] are the TRANSPOSED weights (bf16 row-major), M = frames * S. */
 int iq_ffn_chain_supported(int S, int D, int F);
+int iq_ffn_chain_bwd_partial_rows(int M);
+size_t iq_ffn_chain_gate_bytes(int M, int F);
+int iq_ffn_chain_bwd(const void* dO, const void* W2t, const void* gate_bits, float gate_scale, void* gH, const void* W1t,
+                     const void* residual, const void* z1, const float* mean, const float* rstd, const float* gamma,
+                     const iq_dropout_t* drop, void* dz, void* dy, float* partial, int frames, int S, int D, int F,
+                     iq_stream_t stream);
 int iq_ffn_chain_fwd(const void* X1, const void* W1, const float* b1, const iq_dropout_t* drop1, void* H, const void* W2,
                      const float* b2, const iq_dropout_t* drop2, const float* gamma, const float* beta, float eps, void* Z,
-                     void* X, float* mean, float* rstd, int frames, int S, int D, int F, iq_stream_t stream);
+                     void* X, float* mean, float* rstd, void* gate_bits, int frames, int S, int D, int F, iq_stream_t stream);
 
 /* Weight gradient: dW[N,K] (+)= dY[M,N]^T * X[M,K]; dbias[N] (+)= colsum(dY) (NULL to skip).
  * Split over M into slabs in `ws` (iq_wgrad_ws_bytes), reduced deterministically (no atomics). */

@@ -23,7 +23,7 @@ def dr(site):
 d1, d2 = dr(2), dr(3)
 fn = lambda: L.iq_ffn_chain_fwd(X1.data_ptr(), W1.data_ptr(), b1.data_ptr(), C.byref(d1) if pdrop > 0 else None, H.data_ptr(), W2.data_ptr(), b2.data_ptr(),
                                 C.byref(d2) if pdrop > 0 else None, gm.data_ptr(), bt.data_ptr(), 1e-12, Z.data_ptr(), X.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                frames, S, D, F, st())
+                                None, frames, S, D, F, st())
 for _ in range(5): fn()
 torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -24,7 +24,7 @@ N.check(L.iq_gemm_bf16_ln(H0.data_ptr(), F, W2.data_ptr(), F, b2.data_ptr(), X1.
                           Z0.data_ptr(), X0.data_ptr(), m0.data_ptr(), r0.data_ptr(), M, D, F, st()), "ln")
 H1 = torch.zeros(M, F, device=d, dtype=torch.bfloat16); Z1 = torch.zeros(M, D, device=d, dtype=torch.bfloat16); X2 = torch.zeros_like(Z1); m1 = torch.zeros(M, device=d); r1 = torch.zeros(M, device=d)
 N.check(L.iq_ffn_chain_fwd(X1.data_ptr(), W1.data_ptr(), b1.data_ptr(), C.byref(d1) if pdrop > 0 else None, H1.data_ptr(), W2.data_ptr(), b2.data_ptr(),
-                           C.byref(d2) if pdrop > 0 else None, gm.data_ptr(), bt.data_ptr(), 1e-12, Z1.data_ptr(), X2.data_ptr(), m1.data_ptr(), r1.data_ptr(), frames, S, D, F, st()), "chain")
+                           C.byref(d2) if pdrop > 0 else None, gm.data_ptr(), bt.data_ptr(), 1e-12, Z1.data_ptr(), X2.data_ptr(), m1.data_ptr(), r1.data_ptr(), None, frames, S, D, F, st()), "chain")
 torch.cuda.synchronize()
 for name, a, b in (("H", H0, H1), ("Z", Z0, Z1), ("X", X0, X2)):
     ne = a.view(torch.int16) != b.view(torch.int16)

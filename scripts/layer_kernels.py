@@ -87,7 +87,7 @@ def ffn_chain():
     d1, d2 = dr(2), dr(3)
     us = timeit(lambda: L.iq_ffn_chain_fwd(X1.data_ptr(), W1.data_ptr(), b1.data_ptr(), C.byref(d1) if drop > 0 else None, Hh.data_ptr(),
                                            W2.data_ptr(), b2.data_ptr(), C.byref(d2) if drop > 0 else None, gm.data_ptr(), bt.data_ptr(), 1e-12,
-                                           Z.data_ptr(), X.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, S, D, F, st()))
+                                           Z.data_ptr(), X.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None, B, S, D, F, st()))
     print(f"{'[ffn chain: ffn1 + ffn2 + norm2]':34s} {us:8.1f} us  {(2 * (3 * M * D + M * F + 2 * D * F)) / us / 1e3:8.1f} GB/s  {4 * M * D * F / us / 1e6:8.1f} TFLOP/s", flush=True)
 print(f"D={D} H={H} F={F} S={S} B={B} M={M} drop={drop}")
 nt("qkv projection", 3 * D, D, bias=True)

@@ -363,7 +363,7 @@ def test_ffn_chain_equals_ffn1_then_ffn2_layernorm(L, frames, S, D, F, pdrop):
     mean1 = torch.full((M,), nan, device=dev()); rstd1 = torch.full((M,), nan, device=dev())
     N.check(L.iq_ffn_chain_fwd(X1.data_ptr(), W1.data_ptr(), b1.data_ptr(), C.byref(d1) if pdrop > 0 else None, H1.data_ptr(),
                                W2.data_ptr(), b2.data_ptr(), C.byref(d2) if pdrop > 0 else None, gamma.data_ptr(), beta.data_ptr(),
-                               1e-12, Z1.data_ptr(), X2.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), frames, S, D, F, stream()),
+                               1e-12, Z1.data_ptr(), X2.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), None, frames, S, D, F, stream()),
             "ffn_chain")
     def ties_only(a, b, what, frac, abs_=1e-5):
         ne = a.view(torch.int16) != b.view(torch.int16)
@@ -392,6 +392,70 @@ def test_ffn_chain_equals_ffn1_then_ffn2_layernorm(L, frames, S, D, F, pdrop):
         zb = Z1.double()
         mu = zb.mean(-1, keepdim=True); var = zb.var(-1, unbiased=False, keepdim=True)
         close_bf16(X2, gamma.double() * ((zb - mu) / torch.sqrt(var + 1e-12)) + beta.double(), "X vs fp64")
+
+
+@pytest.mark.parametrize("frames,S,D,F,pdrop", [(256, 197, 192, 768, 0.1), (7, 197, 192, 832, 0.0), (256, 65, 128, 1024, 0.2),
+                                                 (5, 5, 128, 512, 0.0), (3, 224, 192, 128, 0.3), (9, 17, 128, 896, 0.1),
+                                                 (40, 197, 192, 64, 0.1), (2, 1, 192, 256, 0.0)])
+def test_ffn_chain_backward_equals_gate_gemm_then_dgrad_layernorm_backward(L, frames, S, D, F, pdrop):
+    """iq_ffn_chain_bwd (gate data gradient + FFN1 data gradient + residual + norm1 backward in one launch, gate = the "H > 0"
+    bits iq_ffn_chain_fwd leaves) against the two launches it replaces -- iq_gemm_bf16_nt with the gate epilogue on H itself,
+    then iq_gemm_bf16_lnbwd: gH / dZ / dY equal except at rounding ties (k-values enter the MFMAs in another lane-group
+    order), identical dropout masks, gamma / beta partial sums to fp32 summation order; F / 64 = 12, 13, 14 chunks exercise the
+    three phases of the ring in which the tail borrows its scratch."""
+    N = _N()
+    M = frames * S
+    g = torch.Generator(device="cuda").manual_seed(M + D + F)
+    X1 = bf(torch.randn(M, D, device=dev(), generator=g))
+    W1 = bf(torch.randn(F, D, device=dev(), generator=g) / math.sqrt(D))
+    W2 = bf(torch.randn(D, F, device=dev(), generator=g) / math.sqrt(F))
+    b1, b2 = torch.randn(F, device=dev(), generator=g), torch.randn(D, device=dev(), generator=g)
+    gamma = torch.rand(D, device=dev(), generator=g) + 0.5
+    beta = torch.randn(D, device=dev(), generator=g)
+    # forward: H and its gate bits
+    H = torch.empty(M, F, dtype=torch.bfloat16, device=dev()); Zf = torch.empty(M, D, dtype=torch.bfloat16, device=dev()); Xf = torch.empty_like(Zf)
+    mf = torch.empty(M, device=dev()); rf = torch.empty(M, device=dev())
+    gate = torch.zeros(L.iq_ffn_chain_gate_bytes(M, F), dtype=torch.uint8, device=dev())
+    d1 = _drop(3, 1, 2, pdrop)
+    N.check(L.iq_ffn_chain_fwd(X1.data_ptr(), W1.data_ptr(), b1.data_ptr(), C.byref(d1) if pdrop > 0 else None, H.data_ptr(), W2.data_ptr(),
+                               b2.data_ptr(), None, gamma.data_ptr(), beta.data_ptr(), 1e-12, Zf.data_ptr(), Xf.data_ptr(), mf.data_ptr(),
+                               rf.data_ptr(), gate.data_ptr(), frames, S, D, F, stream()), "ffn_chain_fwd")
+    # backward operands
+    dO = bf(torch.randn(M, D, device=dev(), generator=g))
+    W2t = W2.t().contiguous(); W1t = W1.t().contiguous()                 # [F, D], [D, F]
+    R = bf(torch.randn(M, D, device=dev(), generator=g))
+    z = bf(torch.randn(M, D, device=dev(), generator=g) * 1.5 + 0.3)
+    mean = z.float().mean(-1).contiguous(); rstd = (1.0 / torch.sqrt(z.float().var(-1, unbiased=False) + 1e-12)).contiguous()
+    dr = _drop(77, 5, 7, pdrop)
+    scale = 65536.0 / (65536.0 - round(pdrop * 65536)) if pdrop > 0 else 1.0
+    gH0 = run_gemm(L, dO, W2t, M, F, D, gate=H, ldg=F, gate_scale=scale)
+    dz0 = torch.empty_like(z); dy0 = torch.zeros_like(z)
+    part0 = torch.empty(L.iq_gemm_lnbwd_partial_rows(M), 2 * D, device=dev())
+    N.check(L.iq_gemm_bf16_lnbwd(gH0.data_ptr(), F, W1t.data_ptr(), F, R.data_ptr(), D, z.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                 gamma.data_ptr(), C.byref(dr) if pdrop > 0 else None, dz0.data_ptr(), dy0.data_ptr(), part0.data_ptr(),
+                                 M, D, F, stream()), "gemm_lnbwd")
+    nan = float("nan")
+    gH1 = torch.full((M, F), nan, dtype=torch.bfloat16, device=dev()); dz1 = torch.full_like(z, nan); dy1 = torch.zeros_like(z)
+    rows = L.iq_ffn_chain_bwd_partial_rows(M)
+    assert rows == (M + 31) // 32
+    part1 = torch.full((rows, 2 * D), nan, device=dev())
+    N.check(L.iq_ffn_chain_bwd(dO.data_ptr(), W2t.data_ptr(), gate.data_ptr(), scale, gH1.data_ptr(), W1t.data_ptr(), R.data_ptr(), z.data_ptr(),
+                               mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), C.byref(dr) if pdrop > 0 else None, dz1.data_ptr(),
+                               dy1.data_ptr(), part1.data_ptr(), frames, S, D, F, stream()), "ffn_chain_bwd")
+    def ties_only(a, b, what, frac, abs_):
+        ne = a.view(torch.int16) != b.view(torch.int16)
+        assert ne.float().mean().item() <= frac, f"{what}: {ne.float().mean().item():.3g} of the elements differ"
+        excess = (a.float() - b.float()).abs() - (torch.maximum(a.float().abs(), b.float().abs()) * 2 ** -7 + abs_)
+        assert excess.max().item() <= 0.0, f"{what}: more than one bf16 ulp apart ({excess.max().item():.3g})"
+    assert ((gH0 == 0) != (gH1 == 0)).float().mean().item() <= 1e-4, "gate pattern differs"
+    ties_only(gH0, gH1, "gH", 2e-4, 1e-5)
+    ties_only(dz0, dz1, "dZ", 3e-3, 4e-3 * z.float().abs().max().item())
+    if pdrop > 0:
+        assert torch.equal(dy0 == 0, dy1 == 0) or ((dy0 == 0) != (dy1 == 0)).float().mean().item() <= 1e-4
+        ties_only(dy0, dy1, "dY", 3e-3, 6e-3 * z.float().abs().max().item())
+    s0, s1 = part0.sum(0), part1.sum(0)
+    assert torch.isfinite(part1).all()
+    close_f32(s1, s0, "dgamma | dbeta", 2e-3)
 
 
 @pytest.mark.parametrize("M,K,N_", [(5000, 768, 192), (130, 576, 192), (50432, 768, 192), (999, 384, 192), (4000, 1024, 128),

@@ -46,6 +46,7 @@ struct FfnChainParams {
   const bf16* X1; const bf16* W1; const bf16* W2;      // [M,D], [F,D], [D,F]
   const float* b1; const float* b2; const float* gamma; const float* beta;
   bf16* H; bf16* Z; bf16* X; float* mean; float* rstd;  // [M,F], [M,D], [M,D], [M], [M]
+  uint32_t* gate;                                       // optional: "H > 0" bits for iq_ffn_chain_bwd, [ceil(M/32)][F/64][64] dwords
   int M, F;
   float eps;
   int drop1_on, drop2_on; IqRng rng1, rng2; uint32_t thresh1, thresh2; float dscale1, dscale2;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
   constexpr int W1_BYTES = FC_CHUNK * D * 2, W2_BYTES = D * FC_CHUNK * 2, SLOT = W1_BYTES + W2_BYTES;
   constexpr int W1_PIECES = W1_BYTES / 1024, PIECES = SLOT / 1024;     // 1 KiB DMA pieces per chunk: 48 | 32
   constexpr int PPW = (PIECES + NW - 1) / NW;                          // per wave (a wave past the end repeats the last piece)
-  static_assert(PPW + 8 < 64, "counted vmcnt");
+  static_assert(PPW + 10 < 64, "counted vmcnt");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
   // a wave whose 32 rows all exist stores exactly 4 H vectors per chunk: its ring waits can be COUNTED (the stores and the
   // next chunk's pieces stay in flight); a ragged wave waits for everything
   const bool full = row0 + 32 <= p.M;
+  const bool gated = p.gate != nullptr;                 // (kernel-uniform) one more store per chunk
   for (int c = 0; c < nchunk; ++c) {
     // chunk c has landed for this wave (counted: the chunk requested one iteration ago and the H stores of the last two
     // iterations may still be in flight); the barrier makes that true for every wave and says slot (c+2) % 3 = (c-1) % 3 is
@@ -159,6 +161,8 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
 #endif
     if (c == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (b1 image written; the ring's first chunks: above)
     else if (!full || nchunk < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (gated && c + 1 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW + 10) : "memory");
+    else if (gated) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else if (c + 1 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW + 8) : "memory");
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -205,6 +209,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
     }
     // ---- epilogue of the first product; the packed values are the second product's activation fragments ----------------------
     bf16x8 hf[2][2];                                    // [rg][k-step of the chunk]
+    uint32_t gbits = 0;                                 // "hidden unit > 0" (= ReLU and dropout gate of the backward), byte 2 jp + rg
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
       const int col = f0 + 32 * jp + (odd ? 16 + 4 * (g - 1) : 4 * g);       // first of this lane's 8 hidden units
@@ -226,12 +231,19 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
           for (int e = 0; e < 8; ++e) w[e] = ((keep >> e) & 1u) ? w[e] * p.dscale1 : 0.f;
         }
         hf[rg][jp] = pack8(w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gbits |= (w[e] > 0.f ? 1u : 0u) << (8 * (2 * jp + rg) + e);
 #ifndef FC_NO_HSTORE    // (ablation build, timing only, leaves H unwritten)
         if (grow < p.M) *reinterpret_cast<bf16x8*>(p.H + grow * F + col) = hf[rg][jp];
 #endif
       }
     }
     // ---- second product: acc2[rg][j] += H_c x W2 rows 16 j .. +15, hidden units f0 .. f0 + 63 ----------------------------------
+    // one dword per lane and chunk: 256 contiguous bytes per wave (a fifth store per chunk when the caller asks for the bits:
+    // the counted waits above)
+    {
+      if (gated) p.gate[((row0 >> 5) * nchunk + c) * 64 + lane] = gbits;
+    }
     // (same read-ahead: groups of four output tiles; group q = k-step q / NG4, tiles 4 (q % NG4) .. + 3)
     constexpr int NG4 = NT2 / 4, NGRP = 2 * NG4;        // 3 | 2 groups per k-step, 6 | 4 per chunk
     auto read_w2 = [&](int q, bf16x8 (&dst)[4]) {
@@ -325,6 +337,327 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Backward of the same sub-layer's data path, one launch (autograd of position_wise_feed_forward.py:12-17 + the norm1 that
+// feeds it, encoder_layer.py:24-25):
+//     gH[M,F]  = (H > 0) ? (dO[M,D] * W2t[F,D]^T) * gate_scale : 0            bf16, written once (the W1 / W2 weight gradients read it)
+//     dX1[M,D] = gH * W1t[D,F]^T + R                                           fp32, rounded to bf16 as the unfused GEMM stored it
+//     then exactly iq_ln_bwd on it:  g = dX1 * gamma, xhat = (Z1 - mean) * rstd,
+//     dZ = rstd * (g - mean_D(g) - xhat * mean_D(g * xhat)),  dY = dropout1_mask(dZ) * scale,
+//     partial[wave] = sums over the wave's 32 rows of (dX1 * xhat | dX1)      fp32 [2 D]  (norm1's gamma / beta gradient partials)
+// replacing the gate data-gradient GEMM and the FFN1 data-gradient GEMM + LayerNorm backward (gemm_lnbwd.hip): gH no longer
+// makes the round trip through HBM between them.  Same structure as the forward kernel above: dO rows as register
+// fragments, the two transposed weights through the LDS ring, the gated tile handed to the second product in registers.
+// The gate ("H > 0": ReLU and dropout1 of the forward pass at once) is one BIT per hidden unit, written by the forward kernel
+// in this kernel's own wave / chunk / lane order: one dword per lane and chunk instead of four 16-byte rows of H (H itself is
+// read by the weight gradients only; 77.5 MB per layer less for cfg B), and one register instead of sixteen -- with the gate
+// rows resident beside the dO fragments and the accumulators the D = 192 build spilled 150 registers.
+struct FfnChainBwdParams {
+  const bf16* dO; const bf16* W2t; const bf16* W1t;     // [M,D], [F,D], [D,F]
+  const uint32_t* gate; const bf16* R; const bf16* Z1;  // gate bits of the forward kernel, [M,D], [M,D]
+  const float* mean; const float* rstd; const float* gamma;
+  bf16* gH; bf16* dZ; bf16* dY; float* partial;         // [M,F], [M,D], [M,D], [ceil(M/32)][2 D]
+  int M, F;
+  float gate_scale;
+  int drop_on; IqRng rng; uint32_t thresh; float dscale;
+};
+
+template <int D, int NW, bool DROP>
+__global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChainBwdParams p) {
+  constexpr int XCPR = D / 8;
+  constexpr int KS1 = D / 32;
+  constexpr int NT2 = D / 16, NP2 = NT2 / 2;
+  constexpr int W1_BYTES = FC_CHUNK * D * 2, W2_BYTES = D * FC_CHUNK * 2, SLOT = W1_BYTES + W2_BYTES;
+  constexpr int W1_PIECES = W1_BYTES / 1024, PIECES = SLOT / 1024;
+  constexpr int PPW = (PIECES + NW - 1) / NW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c16 = lane & 15;
+  const bool odd = (g & 1) != 0;
+  const int F = p.F;
+  const int nchunk = F / FC_CHUNK;
+  const long row0 = ((long)blockIdx.x * NW + wave) * 32;
+  const bool have = row0 < p.M;
+  const bool full = row0 + 32 <= p.M;
+
+  // ---- weight ring (as in the forward kernel: "W1" = W2t rows f0 .. f0+63 x D, "W2" = W1t rows 0 .. D-1 x hidden f0 .. f0+63) -----
+  // (per-lane source offsets recomputed per chunk: seven resident registers more made the D = 192 build spill)
+  auto issue_chunk = [&](int c) {
+    unsigned char* slot = smem + (c % FC_NS) * SLOT;
+    const char* base1 = reinterpret_cast<const char*>(p.W2t + (long)c * FC_CHUNK * D);
+    const char* base2 = reinterpret_cast<const char*>(p.W1t + (long)c * FC_CHUNK);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = min(wave + i * NW, PIECES - 1);
+      const int lin = pc * 64 + lane;
+      unsigned off;
+      if (pc < W1_PIECES) {
+        const int r = lin / XCPR, sl = lin - r * XCPR;
+        const int q = fc_swz<XCPR>(r, sl);
+        off = (unsigned)((r * D + ((q & ~3) | fc_kperm(q & 3)) * 8) * 2);
+      } else {
+        const int l2 = lin - W1_PIECES * 64;
+        const int r = l2 >> 3, sl = l2 & 7;
+        const int q = fc_swz<8>(r, sl);
+        off = (unsigned)((r * F + ((q & ~3) | fc_kperm(q & 3)) * 8) * 2);
+      }
+      const char* base = pc < W1_PIECES ? base1 : base2;
+      __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(base + off), (lds_void_t*)(slot + pc * 1024), 16, 0, 0);
+    }
+  };
+  issue_chunk(0);
+  if (nchunk > 1) issue_chunk(1);
+
+  // ---- this wave's dO rows as activation fragments; the gate rows of chunk 0 ----------------------------------------------------
+  long rowc[2];
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg) rowc[rg] = min(row0 + rg * 16 + c16, (long)p.M - 1);
+  bf16x8 xf[2][KS1];
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks)
+      xf[rg][ks] = have ? *reinterpret_cast<const bf16x8*>(p.dO + rowc[rg] * D + 32 * ks + 8 * fc_kperm(g)) : bf16x8{};
+  // gate bits of chunk c for this lane's 4 x 8 hidden units: one dword, written by the forward kernel in exactly this wave /
+  // chunk / lane order.  Inline-asm load (invisible to the compiler's wait insertion: a tracked register-destination load in
+  // the loop would make it drain the ring), issued one chunk ahead, retired by the loop's own counted wait.
+  const uint32_t* gate_lane = p.gate + (row0 >> 5) * nchunk * 64 + lane;
+  uint32_t gnext;
+  auto load_gate = [&](int c) {
+    const uint32_t* src = gate_lane + c * 64;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(gnext) : "v"(src) : "memory");
+  };
+  load_gate(0);
+  const IqRng rng = DROP ? rng_resolve(p.rng) : p.rng;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg) {
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) asm volatile("" : "+v"(xf[rg][ks]));
+  }
+  asm volatile("" : "+v"(gnext));
+
+  f32x4 acc2[2][NT2];
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+    for (int j = 0; j < NT2; ++j) acc2[rg][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int c = 0; c < nchunk; ++c) {
+    // Queue of this wave at this point, youngest first: the 4 gH stores of chunk c-1 | the gate load of chunk c | the ring
+    // pieces of chunk c+1 | ...: "at most 4 outstanding" = gate(c) and ring chunk c+1 (hence c) have landed.  A ragged wave's
+    // stores are predicated (their count is not known): it waits for everything.
+    if (c > 0) {
+      if (full) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (c + 2 < nchunk) issue_chunk(c + 2);
+    if (!have) continue;
+    asm volatile("" : "+v"(gnext));                     // (landed: the wait above; defined from here on as far as the compiler knows)
+    const uint32_t gmask = gnext;
+    const unsigned char* W1s = smem + (c % FC_NS) * SLOT;
+    const unsigned char* W2s = W1s + W1_BYTES;
+    const int f0 = c * FC_CHUNK;
+    // ---- first product + gate, 32 hidden units (two column tiles) at a time -- 16 accumulator registers instead of 32: with the
+    //      gate rows (16) beside the 144 of the dO fragments and the second product's accumulators, the wide form spilled ------
+    bf16x8 hf[2][2];
+    bf16x8 wp[2];
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      f32x4 acc1[2][2];
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg) { acc1[rg][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      auto read_w1 = [&](int ks, bf16x8 (&dst)[2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int r = 16 * (2 * jp + t) + c16;
+          dst[t] = *reinterpret_cast<const bf16x8*>(W1s + r * (D * 2) + fc_swz<XCPR>(r, 4 * ks + g) * 16);
+        }
+      };
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) {
+        read_w1(ks, wp);
+        __builtin_amdgcn_sched_barrier(0);              // (pins the reads to their k-step: hoisted together they spill)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc1[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[t], xf[0][ks], acc1[0][t], 0, 0, 0);
+          acc1[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[t], xf[1][ks], acc1[1][t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // gate: ReLU and dropout of the FORWARD hidden unit are both "Hid > 0"; the packed tile feeds the second product
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg) {
+        float w[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float va = acc1[rg][0][r], vb = acc1[rg][1][r];
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
+          w[r] = __uint_as_float(sw[0]);
+          w[4 + r] = __uint_as_float(sw[1]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = ((gmask >> (8 * (2 * jp + rg) + e)) & 1u) ? w[e] * p.gate_scale : 0.f;
+        hf[rg][jp] = pack8(w);
+      }
+    }
+    // the next chunk's gate word, ahead of this chunk's stores in the queue
+    asm volatile("" ::: "memory");
+    if (c + 1 < nchunk) load_gate(c + 1);
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      const int col = f0 + 32 * jp + (odd ? 16 + 4 * (g - 1) : 4 * g);
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg) {
+        const long grow = row0 + rg * 16 + c16;
+        if (grow < p.M) *reinterpret_cast<bf16x8*>(p.gH + grow * F + col) = hf[rg][jp];
+      }
+    }
+    // ---- second product: acc2 += gH_c x W1t rows (model columns) 16 j .. +15, hidden units f0 .. f0 + 63 --------------------------
+    constexpr int NG4 = NT2 / 4, NGRP = 2 * NG4;
+    bf16x8 wq[4];
+    auto read_w2 = [&](int q, bf16x8 (&dst)[4]) {
+      const int jp = q / NG4, j0 = 4 * (q % NG4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = 16 * (j0 + t) + c16;
+        dst[t] = *reinterpret_cast<const bf16x8*>(W2s + r * 128 + fc_swz<8>(r, 4 * jp + g) * 16);
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < NGRP; ++q) {
+      read_w2(q, wq);
+      __builtin_amdgcn_sched_barrier(0);
+      const int jp = q / NG4, j0 = 4 * (q % NG4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc2[0][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[t], hf[0][jp], acc2[0][j0 + t], 0, 0, 0);
+        acc2[1][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[t], hf[1][jp], acc2[1][j0 + t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (!have) return;
+
+  // ---- tail: dX1 = acc2 + R, rounded to bf16 as the unfused data-gradient GEMM stored it, into a wave-private LDS image; then
+  //      ln_bwd_kernel's own arithmetic on it in LayerNorm's layout (a row = 8 lanes x NV 16-byte vectors): the accumulators are
+  //      released at once (doing the LayerNorm in the MFMA register layout -- 96 accumulators + the row's Z and dX -- spilled
+  //      ~80 registers at D = 192, and the allocator then also spilled loop-invariant fragments).  Scratch = the ring slots of
+  //      chunks nchunk-2 and nchunk-3: every wave is past the last hand-over barrier, nobody reads or fills them any more.
+  constexpr int LDI = D;                                // image row (elements; unpadded: exactly four images per ring slot)
+  constexpr int IMG = 32 * LDI * 2;                     // bytes per wave: 12,288 | 8,192
+  static_assert(SLOT % IMG == 0 && FC_MAXW <= 2 * (SLOT / IMG), "whole wave images, seven of them in the two dead ring slots");
+  bf16* img;
+  {
+    const int s2 = (nchunk >= 2 ? nchunk - 2 : 1) % FC_NS, s3 = (nchunk >= 2 ? nchunk : 2) % FC_NS;     // (nchunk - 3) % 3 == nchunk % 3
+    const int per = SLOT / IMG;                         // whole images per slot
+    img = reinterpret_cast<bf16*>(smem + (wave < per ? s2 * SLOT + wave * IMG : s3 * SLOT + (wave - per) * IMG));
+  }
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg) {
+    const long gr = min(row0 + rg * 16 + c16, (long)p.M - 1);
+#pragma unroll
+    for (int jp = 0; jp < NP2; ++jp) {
+      const int col = 32 * jp + (odd ? 16 + 4 * (g - 1) : 4 * g);
+      const bf16x8 res = *reinterpret_cast<const bf16x8*>(p.R + gr * D + col);
+      float w[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float va = acc2[rg][2 * jp][r], vb = acc2[rg][2 * jp + 1][r];
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
+        w[r] = __uint_as_float(sw[0]);
+        w[4 + r] = __uint_as_float(sw[1]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w[e] += (float)res[e];
+      *reinterpret_cast<bf16x8*>(img + (rg * 16 + c16) * LDI + col) = pack8(w);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // wave-private image: the wave's own LDS writes, no barrier
+  {
+    constexpr int LPR = 8, NV = D / (8 * LPR);          // 3 | 2
+    const int lj = lane & 7, rsub = lane >> 3;          // 8 rows per pass, 4 passes
+    const float invD = 1.0f / (float)D;
+    float gmm[NV][8], ag[NV][8], ab[NV][8];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.gamma + (v * LPR + lj) * 8), b4 = *reinterpret_cast<const f32x4*>(p.gamma + (v * LPR + lj) * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { gmm[v][e] = a4[e]; gmm[v][4 + e] = b4[e]; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { ag[v][e] = 0.f; ab[v][e] = 0.f; }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rl = it * 8 + rsub;
+      const long row = row0 + rl;
+      const bool ok = row < p.M;
+      const long gr = min(row, (long)p.M - 1);
+      const float mean = p.mean[gr], rstd = p.rstd[gr];
+      float xh[NV][8], dy[NV][8];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        bf16x8 td = *reinterpret_cast<const bf16x8*>(img + rl * LDI + (v * LPR + lj) * 8);
+        bf16x8 tz = *reinterpret_cast<const bf16x8*>(p.Z1 + gr * D + (v * LPR + lj) * 8);
+        if (!ok) { td = bf16x8{}; tz = bf16x8{}; }
+        unpack8(tz, xh[v]);
+        unpack8(td, dy[v]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[v][e] = ok ? (xh[v][e] - mean) * rstd : 0.f;
+          ag[v][e] += dy[v][e] * xh[v][e];
+          ab[v][e] += dy[v][e];
+          dy[v][e] *= gmm[v][e];
+          s1 += dy[v][e];
+          s2 += dy[v][e] * xh[v][e];
+        }
+      }
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+      const float c1 = s1 * invD, c2 = s2 * invD;
+      if (ok) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = rstd * (dy[v][e] - c1 - xh[v][e] * c2);
+          const long off = row * D + (v * LPR + lj) * 8;
+          *reinterpret_cast<bf16x8*>(p.dZ + off) = pack8(o);
+          if (DROP) {
+            const uint32_t keep = dropout_keep8(rng, (uint64_t)off >> 3, p.thresh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = ((keep >> e) & 1u) ? o[e] * p.dscale : 0.f;
+            *reinterpret_cast<bf16x8*>(p.dY + off) = pack8(o);
+          }
+        }
+      }
+    }
+    // column sums over the wave's 32 rows: lanes with the same lj hold the same columns (8 row slots): fixed-order shuffles
+    float* prow = p.partial + (row0 / 32) * (2 * D);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float a = ag[v][e], b2 = ab[v][e];
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); b2 += __shfl_xor(b2, o, 64); }
+        ag[v][e] = a; ab[v][e] = b2;
+      }
+      if (rsub == 0) {
+        const int c = (v * LPR + lj) * 8;
+        *reinterpret_cast<f32x4*>(prow + c) = f32x4{ag[v][0], ag[v][1], ag[v][2], ag[v][3]};
+        *reinterpret_cast<f32x4*>(prow + c + 4) = f32x4{ag[v][4], ag[v][5], ag[v][6], ag[v][7]};
+        *reinterpret_cast<f32x4*>(prow + D + c) = f32x4{ab[v][0], ab[v][1], ab[v][2], ab[v][3]};
+        *reinterpret_cast<f32x4*>(prow + D + c + 4) = f32x4{ab[v][4], ab[v][5], ab[v][6], ab[v][7]};
+      }
+    }
+  }
+}
+
 // waves per workgroup: 32 rows each; one workgroup per CU (the ring is most of a CU's LDS), so as many waves as it takes to
 // cover M with <= 256 workgroups -- of the instantiated counts {2, 4, 7}
 inline int chain_waves(int M) {
@@ -360,6 +693,33 @@ int launch_chain_d(const FfnChainParams& p, hipStream_t st) {
   }
 }
 
+template <int D, int NW>
+int launch_chain_bwd(const FfnChainBwdParams& p, hipStream_t st) {
+  constexpr int SLOT = 2 * FC_CHUNK * D * 2;
+  const size_t lds = (size_t)FC_NS * SLOT;
+  const long units = ((long)p.M + 31) / 32;
+  const int grid = (int)((units + NW - 1) / NW);
+#define FC_LAUNCHB(DROP_)                                                                                                     \
+  do {                                                                                                                        \
+    auto k = ffn_chain_bwd_kernel<D, NW, DROP_>;                                                                              \
+    static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    (void)attr;                                                                                                               \
+    k<<<grid, NW * 64, lds, st>>>(p);                                                                                         \
+  } while (0)
+  if (p.drop_on) FC_LAUNCHB(true);
+  else FC_LAUNCHB(false);
+#undef FC_LAUNCHB
+  return iq_launch_status();
+}
+template <int D>
+int launch_chain_bwd_d(const FfnChainBwdParams& p, hipStream_t st) {
+  switch (chain_waves(p.M)) {
+    case 2: return launch_chain_bwd<D, 2>(p, st);
+    case 4: return launch_chain_bwd<D, 4>(p, st);
+    default: return launch_chain_bwd<D, FC_MAXW>(p, st);
+  }
+}
+
 }  // namespace
 
 // D = 128 | 192, F a multiple of 64 (S: rows per frame -- any; rows are owned by waves, 32 at a time, regardless of frames)
@@ -370,8 +730,8 @@ extern "C" int iq_ffn_chain_supported(int S, int D, int F) {
 
 extern "C" int iq_ffn_chain_fwd(const void* X1, const void* W1, const float* b1, const iq_dropout_t* drop1, void* H,
                                 const void* W2, const float* b2, const iq_dropout_t* drop2, const float* gamma,
-                                const float* beta, float eps, void* Z, void* X, float* mean, float* rstd, int frames, int S,
-                                int D, int F, iq_stream_t stream) {
+                                const float* beta, float eps, void* Z, void* X, float* mean, float* rstd, void* gate_bits,
+                                int frames, int S, int D, int F, iq_stream_t stream) {
   if (frames <= 0) return IQ_OK;
   if (!X1 || !W1 || !b1 || !H || !W2 || !b2 || !gamma || !beta || !Z || !X || !mean || !rstd) return IQ_ERR_ARG;
   if (!iq_ffn_chain_supported(S, D, F)) return IQ_ERR_UNSUPPORTED;
@@ -382,6 +742,8 @@ extern "C" int iq_ffn_chain_fwd(const void* X1, const void* W1, const float* b1,
   p.X1 = (const bf16*)X1; p.W1 = (const bf16*)W1; p.W2 = (const bf16*)W2;
   p.b1 = b1; p.b2 = b2; p.gamma = gamma; p.beta = beta;
   p.H = (bf16*)H; p.Z = (bf16*)Z; p.X = (bf16*)X; p.mean = mean; p.rstd = rstd;
+  p.gate = (uint32_t*)gate_bits;
+  if ((uintptr_t)gate_bits % 16) return IQ_ERR_ARG;
   p.M = frames * S; p.F = F; p.eps = eps;
   auto fill = [](const iq_dropout_t* d, int* on, IqRng* r, uint32_t* th, float* sc) -> bool {
     *on = 0; *th = 0; *sc = 1.f; *r = IqRng{0, 0, 0, nullptr};
@@ -401,4 +763,42 @@ extern "C" int iq_ffn_chain_fwd(const void* X1, const void* W1, const float* b1,
   const double M = (double)p.M;
   IQ_PROF_K(2.0 * (M * D * 3 + M * F + 2.0 * D * F) + 8.0 * M, 4.0 * M * D * F, "ffn_chain_fwd_kernel<%d, %d, %s>", D, chain_waves(p.M), p.drop1_on ? "true" : "false");
   return D == 192 ? launch_chain_d<192>(p, st) : launch_chain_d<128>(p, st);
+}
+
+extern "C" int iq_ffn_chain_bwd_partial_rows(int M) { return M > 0 ? (M + 31) / 32 : 0; }
+
+extern "C" size_t iq_ffn_chain_gate_bytes(int M, int F) {
+  if (M <= 0 || F <= 0) return 0;
+  return (size_t)((M + 31) / 32) * (size_t)(F / FC_CHUNK) * 64 * sizeof(uint32_t);
+}
+
+extern "C" int iq_ffn_chain_bwd(const void* dO, const void* W2t, const void* gate_bits, float gate_scale, void* gH, const void* W1t,
+                                const void* residual, const void* z1, const float* mean, const float* rstd, const float* gamma,
+                                const iq_dropout_t* drop, void* dz, void* dy, float* partial, int frames, int S, int D, int F,
+                                iq_stream_t stream) {
+  if (frames <= 0) return IQ_OK;
+  if (!dO || !W2t || !gate_bits || !gH || !W1t || !residual || !z1 || !mean || !rstd || !gamma || !dz || !partial) return IQ_ERR_ARG;
+  if (!iq_ffn_chain_supported(S, D, F)) return IQ_ERR_UNSUPPORTED;
+  if (((uintptr_t)dO | (uintptr_t)W2t | (uintptr_t)W1t | (uintptr_t)gate_bits | (uintptr_t)gH | (uintptr_t)residual | (uintptr_t)z1 |
+       (uintptr_t)dz | (uintptr_t)dy | (uintptr_t)gamma | (uintptr_t)partial) % 16) return IQ_ERR_ARG;
+  if ((long)frames * S > 0x7FFFFFFFL) return IQ_ERR_UNSUPPORTED;
+  FfnChainBwdParams p = {};
+  p.dO = (const bf16*)dO; p.W2t = (const bf16*)W2t; p.W1t = (const bf16*)W1t;
+  p.gate = (const uint32_t*)gate_bits; p.R = (const bf16*)residual; p.Z1 = (const bf16*)z1;
+  p.mean = mean; p.rstd = rstd; p.gamma = gamma;
+  p.gH = (bf16*)gH; p.dZ = (bf16*)dz; p.dY = (bf16*)dy; p.partial = partial;
+  p.M = frames * S; p.F = F; p.gate_scale = gate_scale;
+  if (drop && drop->p > 0.f) {
+    if (drop->p >= 1.f || !dy) return IQ_ERR_ARG;
+    p.drop_on = 1;
+    p.rng.seed = drop->seed; p.rng.step = drop->step; p.rng.site = drop->site; p.rng.step_dev = drop->step_dev;
+    p.thresh = dropout_thresh(drop->p);
+    p.dscale = dropout_scale(drop->p);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  IQ_PROF(IQ_FAM_GEMM_NT, st);
+  const double M = (double)p.M;
+  IQ_PROF_K(2.0 * (M * D * (4 + (p.drop_on ? 1 : 0)) + 2.0 * M * F + 2.0 * D * F) + 8.0 * M, 4.0 * M * D * F, "ffn_chain_bwd_kernel<%d, %d, %s>", D,
+            chain_waves(p.M), p.drop_on ? "true" : "false");
+  return D == 192 ? launch_chain_bwd_d<192>(p, st) : launch_chain_bwd_d<128>(p, st);
 }

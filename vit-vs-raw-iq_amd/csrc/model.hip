@@ -45,7 +45,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsPlan {
   size_t step_ctr, patches, x0, head_feat, head_stat;
-  struct L { size_t qkv, att, lse, z1, mean1, rstd1, x1, hid, z2, mean2, rstd2, x2; };
+  struct L { size_t qkv, att, lse, z1, mean1, rstd1, x1, hid, gate, z2, mean2, rstd2, x2; };
   std::vector<L> layers;
   size_t gA, gB, gAtt, demb, wgrad_ws, wgrad_ws_bytes, ln_part[2], embw_scratch;
   // dY operands of a layer's weight gradients (live from their producer to the layer's grouped weight-gradient launch)
@@ -147,6 +147,7 @@ struct iq_model {
   uint32_t* step_ctr = nullptr;   // caller-owned persistent device counter of the dropout step (iq_model_bind_step_counter)
   uint64_t last_seed = 0;   // seed of the last training forward; backward regenerates the same masks
   bool last_tr = false;     // whether the last forward applied dropout
+  bool last_train_fwd = false;   // a forward has run in this workspace (the one-launch feed-forward's gate bits exist)
 
   iq_dropout_t bwd_site(uint32_t id, const uint32_t* step_dev, bool tr) const {
     iq_dropout_t d;
@@ -196,6 +197,7 @@ WsPlan plan_ws(const iq_model* m, int B) {
     l.rstd1 = take(M * 4);
     l.x1 = take(M * D * 2);
     l.hid = take(M * F * 2);
+    l.gate = take(iq_ffn_chain_gate_bytes((int)M, (int)F));     // "hid > 0" bits of the one-launch feed-forward (forward -> backward)
     l.z2 = take(M * D * 2);
     l.mean2 = take(M * 4);
     l.rstd2 = take(M * 4);
@@ -228,7 +230,9 @@ WsPlan plan_ws(const iq_model* m, int B) {
   w.wgrad_ws = take(wb);
   // norm2 / norm1 partial rows, reduced with the layer's slabs: the stand-alone kernel caps its grid (one row per
   // block), the fused data-gradient GEMM + LayerNorm backward writes one row per row block of M
-  const size_t ln_rows_fused = (size_t)iq_gemm_lnbwd_partial_rows((int)M) * 2 * D * sizeof(float);
+  size_t ln_rows_fused = (size_t)iq_gemm_lnbwd_partial_rows((int)M);
+  if ((size_t)iq_ffn_chain_bwd_partial_rows((int)M) > ln_rows_fused) ln_rows_fused = (size_t)iq_ffn_chain_bwd_partial_rows((int)M);
+  ln_rows_fused *= 2 * D * sizeof(float);
   const size_t ln_bytes = ln_rows_fused > iq_ln_bwd_ws_bytes((int)D) ? ln_rows_fused : iq_ln_bwd_ws_bytes((int)D);
   for (int k = 0; k < 2; ++k) w.ln_part[k] = take(ln_bytes);
   w.embw_scratch = take((size_t)D * m->Ppad * 4 + 256);
@@ -460,6 +464,7 @@ extern "C" int iq_model_forward(iq_model_t* m, const float* src, int batch, void
   // value), else a slot of the workspace
   uint32_t* step_dev = m->step_ctr ? m->step_ctr : (uint32_t*)(ws + w.step_ctr);
   m->last_tr = tr;
+  m->last_train_fwd = true;      // (every forward leaves the gate bits of the one-launch feed-forward where it runs)
   if (tr) {
     set_u32_kernel<<<1, 64, 0, st>>>(step_dev, step, step == 0xFFFFFFFFu ? 1 : 0);
     m->last_seed = seed;
@@ -505,7 +510,7 @@ extern "C" int iq_model_forward(iq_model_t* m, const float* src, int batch, void
     const iq_dropout_t dr2 = site(m, seed, step_dev, 3 + 3 * l, tr);
     if (use_ffn_chain(M, S, D, F)) {
       IQ_TRY(iq_ffn_chain_fwd(ws + a.x1, m->sh(o.w1), P + o.b1, &drh, ws + a.hid, m->sh(o.w2), P + o.b2, &dr2, P + o.g2, P + o.be2,
-                              1e-12f, ws + a.z2, ws + a.x2, (float*)(ws + a.mean2), (float*)(ws + a.rstd2), B, S, D, F, stream),
+                              1e-12f, ws + a.z2, ws + a.x2, (float*)(ws + a.mean2), (float*)(ws + a.rstd2), ws + a.gate, B, S, D, F, stream),
              "ffn chain + norm2");
     } else {
       memset(&e, 0, sizeof(e));
@@ -612,23 +617,30 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
         {gQKV, 3 * D, xin, D, G + o.wqkv, G + o.bqkv, 3 * D, D}};     // attention.w_q|w_k|w_v
     // the LayerNorm gamma/beta partial rows of this layer ride on the same reduce launch
     const int rows2 = norm2_here ? iq_ln_bwd_partial_rows(M, D) : iq_gemm_lnbwd_partial_rows(M);
-    const int rows1 = fuse1 ? iq_gemm_lnbwd_partial_rows(M) : iq_ln_bwd_partial_rows(M, D);
+    // the one-launch feed-forward backward (ffn_chain.hip) where the forward ran its one-launch counterpart (it left the gate bits)
+    const bool chain = fuse1 && m->last_train_fwd && use_ffn_chain(M, S, D, F);
+    const int rows1 = chain ? iq_ffn_chain_bwd_partial_rows(M) : fuse1 ? iq_gemm_lnbwd_partial_rows(M) : iq_ln_bwd_partial_rows(M, D);
     const iq_reduce_seg_t lnseg[4] = {{lp2, rows2, 2L * D, G + o.g2, D}, {lp2 + D, rows2, 2L * D, G + o.be2, D},
                                       {lp1, rows1, 2L * D, G + o.g1, D}, {lp1 + D, rows1, 2L * D, G + o.be1, D}};
-    memset(&e, 0, sizeof(e));
-    e.gate = ws + a.hid; e.ldg = F; e.gate_scale = dscale;
-    IQ_TRY(iq_gemm_bf16_nt(dO2, D, m->sht(o.t_w2), D, gH, F, M, F, D, &e, stream), "ffn2 dgrad");
-    // FFN1 data gradient (+ the residual-path gradient gZ) and norm1 backward (+ dropout1 mask)
     const iq_dropout_t dr1 = m->bwd_site(1 + 3 * l, step_dev, tr);
-    if (fuse1) {
-      IQ_TRY(iq_gemm_bf16_lnbwd(gH, F, m->sht(o.t_w1), F, gZ, D, ws + a.z1, (const float*)(ws + a.mean1),
-                                (const float*)(ws + a.rstd1), P + o.g1, &dr1, gZ1, gY1, lp1, M, D, F, stream), "ffn1 dgrad + norm1 bwd");
+    if (chain) {
+      IQ_TRY(iq_ffn_chain_bwd(dO2, m->sht(o.t_w2), ws + a.gate, dscale, gH, m->sht(o.t_w1), gZ, ws + a.z1, (const float*)(ws + a.mean1),
+                              (const float*)(ws + a.rstd1), P + o.g1, &dr1, gZ1, gY1, lp1, B, S, D, F, stream), "ffn chain bwd + norm1 bwd");
     } else {
       memset(&e, 0, sizeof(e));
-      e.residual = gZ; e.ldr = D;
-      IQ_TRY(iq_gemm_bf16_nt(gH, F, m->sht(o.t_w1), F, ws + w.gB, D, M, D, F, &e, stream), "ffn1 dgrad");
-      IQ_TRY(iq_ln_bwd(ws + w.gB, ws + a.z1, (const float*)(ws + a.mean1), (const float*)(ws + a.rstd1), P + o.g1,
-                       gZ1, gY1, &dr1, nullptr, nullptr, lp1, accumulate, M, D, stream), "norm1 bwd");
+      e.gate = ws + a.hid; e.ldg = F; e.gate_scale = dscale;
+      IQ_TRY(iq_gemm_bf16_nt(dO2, D, m->sht(o.t_w2), D, gH, F, M, F, D, &e, stream), "ffn2 dgrad");
+      // FFN1 data gradient (+ the residual-path gradient gZ) and norm1 backward (+ dropout1 mask)
+      if (fuse1) {
+        IQ_TRY(iq_gemm_bf16_lnbwd(gH, F, m->sht(o.t_w1), F, gZ, D, ws + a.z1, (const float*)(ws + a.mean1),
+                                  (const float*)(ws + a.rstd1), P + o.g1, &dr1, gZ1, gY1, lp1, M, D, F, stream), "ffn1 dgrad + norm1 bwd");
+      } else {
+        memset(&e, 0, sizeof(e));
+        e.residual = gZ; e.ldr = D;
+        IQ_TRY(iq_gemm_bf16_nt(gH, F, m->sht(o.t_w1), F, ws + w.gB, D, M, D, F, &e, stream), "ffn1 dgrad");
+        IQ_TRY(iq_ln_bwd(ws + w.gB, ws + a.z1, (const float*)(ws + a.mean1), (const float*)(ws + a.rstd1), P + o.g1,
+                         gZ1, gY1, &dr1, nullptr, nullptr, lp1, accumulate, M, D, stream), "norm1 bwd");
+      }
     }
     IQ_TRY(iq_gemm_bf16_nt(dAo, D, m->sht(o.t_wo), D, ws + w.gAtt, D, M, D, D, nullptr, stream), "out-proj dgrad");
     IQ_TRY(iq_attn_bwd(ws + a.qkv, ws + a.att, ws + w.gAtt, (const float*)(ws + a.lse), gQKV, B, S, H, m->dh, stream), "attention bwd");
