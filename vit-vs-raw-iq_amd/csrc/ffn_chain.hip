@@ -32,6 +32,8 @@
 // every k-step exposed an L2 round trip, and registers left no room to look further ahead.  A ring in LDS costs no registers.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "iqvit.h"
 #include "prof.h"
@@ -59,6 +61,20 @@ struct FfnChainParams {
 template <int CPR> __device__ __forceinline__ int fc_swz(int row, int ch) {
   return CPR == 16 ? (ch ^ (row & 15)) : CPR == 8 ? (ch ^ ((row >> 1) & 7)) : ((ch & ~7) | ((ch & 7) ^ ((row >> 1) & 7)));
 }
+// Weight-fragment reads are inline asm with COUNTED lgkmcnt waits: for builtin LDS reads in these loops hipcc waits
+// lgkmcnt(0) before every MFMA group, i.e. also for the fragments it has just requested for the NEXT group (the read-ahead
+// bought nothing: 60.9 vs 65.9 us; without MFMAs, stores and ring the loop still took 1.7 us per chunk, all of it LDS
+// latency).  LDS returns in order: "at most N outstanding" retires everything older.  OFF = compile-time byte offset.
+template <int OFF>
+__device__ __forceinline__ void lds_read128(bf16x8& dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+#define FC_LGKM_WAIT(N)                                  \
+  do {                                                   \
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                   \
+  } while (0)
+
 // hidden-unit / column offset (in units of 8) of lane group g inside a 32-wide k-step: {0, 16, 8, 24} / 8
 __device__ __forceinline__ int fc_kperm(int g) { return ((g & 1) << 1) | (g >> 1); }
 
@@ -88,22 +104,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
   // ---- weight ring: this wave's PPW pieces of every chunk; per-lane source offsets are chunk-invariant ------------------------
   // image position (row r, slot s) holds "slot-order" chunk q = swz(r, s), i.e. the k-chunk lane group (q & 3) reads in
   // k-step (q >> 2): natural chunk 4 (q >> 2) + kperm(q & 3)
-  unsigned poff[PPW];                                   // bytes from W1 + f0 * D (W1 pieces) or W2 + f0 (W2 pieces)
-#pragma unroll
-  for (int i = 0; i < PPW; ++i) {
-    const int pc = min(wave + i * NW, PIECES - 1);
-    const int lin = pc * 64 + lane;
-    if (pc < W1_PIECES) {                               // W1 rows f0 .. f0 + 63, all D columns
-      const int r = lin / XCPR, sl = lin - r * XCPR;
-      const int q = fc_swz<XCPR>(r, sl);
-      poff[i] = (unsigned)((r * D + ((q & ~3) | fc_kperm(q & 3)) * 8) * 2);
-    } else {                                            // W2 rows 0 .. D - 1, columns f0 .. f0 + 63
-      const int l2 = lin - W1_PIECES * 64;
-      const int r = l2 >> 3, sl = l2 & 7;
-      const int q = fc_swz<8>(r, sl);
-      poff[i] = (unsigned)((r * F + ((q & ~3) | fc_kperm(q & 3)) * 8) * 2);
-    }
-  }
+  // (per-lane source offsets are recomputed per chunk: a dozen integer instructions per piece against seven resident registers)
   auto issue_chunk = [&](int c) {
     unsigned char* slot = smem + (c % FC_NS) * SLOT;
     const char* base1 = reinterpret_cast<const char*>(p.W1 + (long)c * FC_CHUNK * D);
@@ -111,8 +112,20 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int pc = min(wave + i * NW, PIECES - 1);    // wave-uniform
+      const int lin = pc * 64 + lane;
+      unsigned off;
+      if (pc < W1_PIECES) {                             // W1 rows f0 .. f0 + 63, all D columns
+        const int r = lin / XCPR, sl = lin - r * XCPR;
+        const int q = fc_swz<XCPR>(r, sl);
+        off = (unsigned)((r * D + ((q & ~3) | fc_kperm(q & 3)) * 8) * 2);
+      } else {                                          // W2 rows 0 .. D - 1, columns f0 .. f0 + 63
+        const int l2 = lin - W1_PIECES * 64;
+        const int r = l2 >> 3, sl = l2 & 7;
+        const int q = fc_swz<8>(r, sl);
+        off = (unsigned)((r * F + ((q & ~3) | fc_kperm(q & 3)) * 8) * 2);
+      }
       const char* base = pc < W1_PIECES ? base1 : base2;
-      __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(base + poff[i]), (lds_void_t*)(slot + pc * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(base + off), (lds_void_t*)(slot + pc * 1024), 16, 0, 0);
     }
   };
   issue_chunk(0);
@@ -147,11 +160,23 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
   for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
     for (int j = 0; j < NT2; ++j) acc2[rg][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // slot-relative byte offsets of this lane's fragment reads: row c16 of a 16-row tile (tiles add a compile-time offset: the
+  // swizzle only looks at (row >> 1) & 7 = (c16 >> 1) & 7), k-step ks of the W1 image / jp of the W2 image
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  uint32_t w1off[KS1], w2off[2];
+#pragma unroll
+  for (int ks = 0; ks < KS1; ++ks) w1off[ks] = (uint32_t)(c16 * (D * 2) + fc_swz<XCPR>(c16, 4 * ks + g) * 16);
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp) w2off[jp] = (uint32_t)(W1_BYTES + c16 * 128 + fc_swz<8>(c16, 4 * jp + g) * 16);
 
   // a wave whose 32 rows all exist stores exactly 4 H vectors per chunk: its ring waits can be COUNTED (the stores and the
   // next chunk's pieces stay in flight); a ragged wave waits for everything
   const bool full = row0 + 32 <= p.M;
   const bool gated = p.gate != nullptr;                 // (kernel-uniform) one more store per chunk
+  // (Dropout of the hidden activation: four Philox calls per lane and chunk, ~1,800 cycles of integer multiplies, 13-18 of the
+  //  kernel's ~62 us.  Computing them one chunk ahead -- all four before the second product, or one call after each of four
+  //  MFMA groups "in the shadow of the matrix pipe" -- measured SLOWER both times (71.8 and 68.5 against 63.6 us): the vector
+  //  ALU is the shared resource, MFMA issue needs its slots too.  They stay in the epilogue, where their result is used.)
   for (int c = 0; c < nchunk; ++c) {
     // chunk c has landed for this wave (counted: the chunk requested one iteration ago and the H stores of the last two
     // iterations may still be in flight); the barrier makes that true for every wave and says slot (c+2) % 3 = (c-1) % 3 is
@@ -172,46 +197,40 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
   ring_done:
 #endif
     if (!have) continue;
-    const unsigned char* W1s = smem + (c % FC_NS) * SLOT;
-    const unsigned char* W2s = W1s + W1_BYTES;
     const int f0 = c * FC_CHUNK;
-    // ---- first product: acc1[rg][t] = X1 rows x hidden units f0 + 16 t .. +15 -------------------------------------------------
-    f32x4 acc1[2][4];
-#pragma unroll
-    for (int rg = 0; rg < 2; ++rg)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc1[rg][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // weight fragments of k-step ks + 1 are read (4 x ds_read_b128) before the 8 MFMAs of k-step ks are issued: left to
-    // itself the compiler read two fragments at a time and drained lgkmcnt before every four MFMAs
-    bf16x8 wq[2][4];
-    auto read_w1 = [&](int ks, bf16x8 (&dst)[4]) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int r = 16 * t + c16;
-        dst[t] = *reinterpret_cast<const bf16x8*>(W1s + r * (D * 2) + fc_swz<XCPR>(r, 4 * ks + g) * 16);
-      }
-    };
-    read_w1(0, wq[0]);
-#pragma unroll
-    for (int ks = 0; ks < KS1; ++ks) {
-      if (ks + 1 < KS1) read_w1(ks + 1, wq[(ks + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-#ifdef FC_NO_MFMA      // ablation build (timing only)
-        asm volatile("" :: "v"(wq[ks & 1][t]));
-#else
-        acc1[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ks & 1][t], xf[0][ks], acc1[0][t], 0, 0, 0);
-        acc1[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ks & 1][t], xf[1][ks], acc1[1][t], 0, 0, 0);
-#endif
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- epilogue of the first product; the packed values are the second product's activation fragments ----------------------
+    // ---- first product + its epilogue, 32 hidden units (two column tiles) at a time: 16 accumulator registers and a 16-register
+    //      read-ahead instead of 32 + 32 (the wide form left no room for the Philox temporaries between the MFMA groups).  The
+    //      packed values are the second product's activation fragments. -------------------------------------------------------
+    const uint32_t slot_addr = lds0 + (c % FC_NS) * SLOT;
     bf16x8 hf[2][2];                                    // [rg][k-step of the chunk]
     uint32_t gbits = 0;                                 // "hidden unit > 0" (= ReLU and dropout gate of the backward), byte 2 jp + rg
+    bf16x8 wp[2][2];
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
+      f32x4 acc1[2][2];
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg) { acc1[rg][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      auto read_w1 = [&](int ks, bf16x8 (&dst)[2]) {
+        const uint32_t a0 = slot_addr + w1off[ks];
+        if (jp == 0) { lds_read128<0 * 16 * D * 2>(dst[0], a0); lds_read128<1 * 16 * D * 2>(dst[1], a0); }
+        else { lds_read128<2 * 16 * D * 2>(dst[0], a0); lds_read128<3 * 16 * D * 2>(dst[1], a0); }
+      };
+      read_w1(0, wp[0]);
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) {
+        if (ks + 1 < KS1) { read_w1(ks + 1, wp[(ks + 1) & 1]); FC_LGKM_WAIT(2); }
+        else FC_LGKM_WAIT(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#ifdef FC_NO_MFMA      // ablation build (timing only)
+          asm volatile("" :: "v"(wp[ks & 1][t]));
+#else
+          acc1[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[0][ks], acc1[0][t], 0, 0, 0);
+          acc1[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[1][ks], acc1[1][t], 0, 0, 0);
+#endif
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       const int col = f0 + 32 * jp + (odd ? 16 + 4 * (g - 1) : 4 * g);       // first of this lane's 8 hidden units
       const f32x4 b_lo = *reinterpret_cast<const f32x4*>(b1s + col), b_hi = *reinterpret_cast<const f32x4*>(b1s + col + 4);
 #pragma unroll
@@ -219,7 +238,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
         float w[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float va = acc1[rg][2 * jp][r], vb = acc1[rg][2 * jp + 1][r];
+          const float va = acc1[rg][0][r], vb = acc1[rg][1][r];
           const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
           w[r] = fmaxf(__uint_as_float(sw[0]) + b_lo[r], 0.f);
           w[4 + r] = fmaxf(__uint_as_float(sw[1]) + b_hi[r], 0.f);
@@ -238,7 +257,6 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
 #endif
       }
     }
-    // ---- second product: acc2[rg][j] += H_c x W2 rows 16 j .. +15, hidden units f0 .. f0 + 63 ----------------------------------
     // one dword per lane and chunk: 256 contiguous bytes per wave (a fifth store per chunk when the caller asks for the bits:
     // the counted waits above)
     {
@@ -246,31 +264,37 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
     }
     // (same read-ahead: groups of four output tiles; group q = k-step q / NG4, tiles 4 (q % NG4) .. + 3)
     constexpr int NG4 = NT2 / 4, NGRP = 2 * NG4;        // 3 | 2 groups per k-step, 6 | 4 per chunk
-    auto read_w2 = [&](int q, bf16x8 (&dst)[4]) {
-      const int jp = q / NG4, j0 = 4 * (q % NG4);
+    bf16x8 wq[2][4];
+    auto read_w2 = [&](auto qc, bf16x8 (&dst)[4]) {
+      constexpr int q = decltype(qc)::value;
+      constexpr int jp = q / NG4, j0 = 4 * (q % NG4);
+      const uint32_t a0 = slot_addr + w2off[jp];
+      lds_read128<(j0 + 0) * 16 * 128>(dst[0], a0);
+      lds_read128<(j0 + 1) * 16 * 128>(dst[1], a0);
+      lds_read128<(j0 + 2) * 16 * 128>(dst[2], a0);
+      lds_read128<(j0 + 3) * 16 * 128>(dst[3], a0);
+    };
+    auto p2 = [&](auto self, auto qc) -> void {
+      constexpr int q = decltype(qc)::value;
+      if constexpr (q < NGRP) {
+        if constexpr (q + 1 < NGRP) { read_w2(std::integral_constant<int, q + 1>{}, wq[(q + 1) & 1]); FC_LGKM_WAIT(4); }
+        else FC_LGKM_WAIT(0);
+        constexpr int jp = q / NG4, j0 = 4 * (q % NG4);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int r = 16 * (j0 + t) + c16;
-        dst[t] = *reinterpret_cast<const bf16x8*>(W2s + r * 128 + fc_swz<8>(r, 4 * jp + g) * 16);
+        for (int t = 0; t < 4; ++t) {
+#ifdef FC_NO_MFMA
+          asm volatile("" :: "v"(wq[q & 1][t]), "v"(hf[0][jp]), "v"(hf[1][jp]));
+#else
+          acc2[0][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 1][t], hf[0][jp], acc2[0][j0 + t], 0, 0, 0);
+          acc2[1][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 1][t], hf[1][jp], acc2[1][j0 + t], 0, 0, 0);
+#endif
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        self(self, std::integral_constant<int, q + 1>{});
       }
     };
-    read_w2(0, wq[0]);
-#pragma unroll
-    for (int q = 0; q < NGRP; ++q) {
-      if (q + 1 < NGRP) read_w2(q + 1, wq[(q + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-      const int jp = q / NG4, j0 = 4 * (q % NG4);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-#ifdef FC_NO_MFMA
-        asm volatile("" :: "v"(wq[q & 1][t]), "v"(hf[0][jp]), "v"(hf[1][jp]));
-#else
-        acc2[0][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 1][t], hf[0][jp], acc2[0][j0 + t], 0, 0, 0);
-        acc2[1][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 1][t], hf[1][jp], acc2[1][j0 + t], 0, 0, 0);
-#endif
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    read_w2(std::integral_constant<int, 0>{}, wq[0]);
+    p2(p2, std::integral_constant<int, 0>{});
   }
   if (!have) return;
 
@@ -443,6 +467,13 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
   for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
     for (int j = 0; j < NT2; ++j) acc2[rg][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // slot-relative byte offsets of this lane's fragment reads (as in the forward kernel)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  uint32_t w1off[KS1], w2off[2];
+#pragma unroll
+  for (int ks = 0; ks < KS1; ++ks) w1off[ks] = (uint32_t)(c16 * (D * 2) + fc_swz<XCPR>(c16, 4 * ks + g) * 16);
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp) w2off[jp] = (uint32_t)(W1_BYTES + c16 * 128 + fc_swz<8>(c16, 4 * jp + g) * 16);
 
   for (int c = 0; c < nchunk; ++c) {
     // Queue of this wave at this point, youngest first: the 4 gH stores of chunk c-1 | the gate load of chunk c | the ring
@@ -458,33 +489,31 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
     if (!have) continue;
     asm volatile("" : "+v"(gnext));                     // (landed: the wait above; defined from here on as far as the compiler knows)
     const uint32_t gmask = gnext;
-    const unsigned char* W1s = smem + (c % FC_NS) * SLOT;
-    const unsigned char* W2s = W1s + W1_BYTES;
     const int f0 = c * FC_CHUNK;
     // ---- first product + gate, 32 hidden units (two column tiles) at a time -- 16 accumulator registers instead of 32: with the
     //      gate rows (16) beside the 144 of the dO fragments and the second product's accumulators, the wide form spilled ------
+    const uint32_t slot_addr = lds0 + (c % FC_NS) * SLOT;
     bf16x8 hf[2][2];
-    bf16x8 wp[2];
+    bf16x8 wp[2][2];
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
       f32x4 acc1[2][2];
 #pragma unroll
       for (int rg = 0; rg < 2; ++rg) { acc1[rg][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       auto read_w1 = [&](int ks, bf16x8 (&dst)[2]) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int r = 16 * (2 * jp + t) + c16;
-          dst[t] = *reinterpret_cast<const bf16x8*>(W1s + r * (D * 2) + fc_swz<XCPR>(r, 4 * ks + g) * 16);
-        }
+        const uint32_t a0 = slot_addr + w1off[ks];
+        if (jp == 0) { lds_read128<0 * 16 * D * 2>(dst[0], a0); lds_read128<1 * 16 * D * 2>(dst[1], a0); }
+        else { lds_read128<2 * 16 * D * 2>(dst[0], a0); lds_read128<3 * 16 * D * 2>(dst[1], a0); }
       };
+      read_w1(0, wp[0]);
 #pragma unroll
       for (int ks = 0; ks < KS1; ++ks) {
-        read_w1(ks, wp);
-        __builtin_amdgcn_sched_barrier(0);              // (pins the reads to their k-step: hoisted together they spill)
+        if (ks + 1 < KS1) { read_w1(ks + 1, wp[(ks + 1) & 1]); FC_LGKM_WAIT(2); }
+        else FC_LGKM_WAIT(0);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          acc1[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[t], xf[0][ks], acc1[0][t], 0, 0, 0);
-          acc1[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[t], xf[1][ks], acc1[1][t], 0, 0, 0);
+          acc1[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[0][ks], acc1[0][t], 0, 0, 0);
+          acc1[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[1][ks], acc1[1][t], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -518,27 +547,33 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
     }
     // ---- second product: acc2 += gH_c x W1t rows (model columns) 16 j .. +15, hidden units f0 .. f0 + 63 --------------------------
     constexpr int NG4 = NT2 / 4, NGRP = 2 * NG4;
-    bf16x8 wq[4];
-    auto read_w2 = [&](int q, bf16x8 (&dst)[4]) {
-      const int jp = q / NG4, j0 = 4 * (q % NG4);
+    bf16x8 wq[2][4];
+    auto read_w2 = [&](auto qc, bf16x8 (&dst)[4]) {
+      constexpr int q = decltype(qc)::value;
+      constexpr int jp = q / NG4, j0 = 4 * (q % NG4);
+      const uint32_t a0 = slot_addr + w2off[jp];
+      lds_read128<(j0 + 0) * 16 * 128>(dst[0], a0);
+      lds_read128<(j0 + 1) * 16 * 128>(dst[1], a0);
+      lds_read128<(j0 + 2) * 16 * 128>(dst[2], a0);
+      lds_read128<(j0 + 3) * 16 * 128>(dst[3], a0);
+    };
+    auto p2 = [&](auto self, auto qc) -> void {
+      constexpr int q = decltype(qc)::value;
+      if constexpr (q < NGRP) {
+        if constexpr (q + 1 < NGRP) { read_w2(std::integral_constant<int, q + 1>{}, wq[(q + 1) & 1]); FC_LGKM_WAIT(4); }
+        else FC_LGKM_WAIT(0);
+        constexpr int jp = q / NG4, j0 = 4 * (q % NG4);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int r = 16 * (j0 + t) + c16;
-        dst[t] = *reinterpret_cast<const bf16x8*>(W2s + r * 128 + fc_swz<8>(r, 4 * jp + g) * 16);
+        for (int t = 0; t < 4; ++t) {
+          acc2[0][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 1][t], hf[0][jp], acc2[0][j0 + t], 0, 0, 0);
+          acc2[1][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 1][t], hf[1][jp], acc2[1][j0 + t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        self(self, std::integral_constant<int, q + 1>{});
       }
     };
-#pragma unroll
-    for (int q = 0; q < NGRP; ++q) {
-      read_w2(q, wq);
-      __builtin_amdgcn_sched_barrier(0);
-      const int jp = q / NG4, j0 = 4 * (q % NG4);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        acc2[0][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[t], hf[0][jp], acc2[0][j0 + t], 0, 0, 0);
-        acc2[1][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[t], hf[1][jp], acc2[1][j0 + t], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    read_w2(std::integral_constant<int, 0>{}, wq[0]);
+    p2(p2, std::integral_constant<int, 0>{});
   }
   if (!have) return;
 
