@@ -182,13 +182,14 @@ def cpu_baseline(kind, kw, drop, wd, gpu_batch, budget_s=40.0):
         shape = (b, kw["in_channels"], kw["img_size_h"], kw["img_size_w"]) if kind == "vit" else (b, kw["in_channels"], kw["seq_length"])
         return torch.randn(*shape, generator=g), torch.randint(0, kw["num_classes"], (b,), generator=g)
 
-    # probe: a small step to size the batch (its time per frame over-estimates the large batch's)
-    pb = min(gpu_batch, 8 if kw["d_model"] <= 256 else 2)
+    # probe: a small step to size the batch.  Its time per frame UNDER-estimates the large batch's on a wide model (cfg B: 36
+    # frames/s at batch 8, 15 at batch 256 -- activations fall out of the host caches): the estimate is doubled.
+    pb = min(gpu_batch, 16 if kw["d_model"] <= 256 else 2)
     x, y = batch_of(pb)
     O.train_step(cfg, sd, st, x, y, weight_decay=wd)
     t0 = time.perf_counter()
     O.train_step(cfg, sd, st, x, y, weight_decay=wd)
-    per_frame = (time.perf_counter() - t0) / pb
+    per_frame = 2.0 * (time.perf_counter() - t0) / pb
     step_cap = min(60.0, budget_s / 4.0)           # a step under 60 s; here also 1 + 3 steps inside the budget
     b = int(max(1, min(gpu_batch, step_cap / per_frame)))
     x, y = batch_of(b)
@@ -357,6 +358,18 @@ def measure(a, config_id, dev, rank, world, steps, warmup, prof_steps, want_cpu)
         per_step = {f: ms[i] / prof_steps for i, f in enumerate(FAMILIES)}
         fused_ln = int(cnt[FAMILIES.index("ln_fwd")]) == 0
         work = family_work(geo, B, drop > 0, fused_ln, int(cnt[FAMILIES.index("ln_bwd")]) // prof_steps)
+        # Algorithmic bytes / flops per family as the launch sites themselves recorded them (operands read once, results written
+        # once, per launch: iq_prof_kernels) -- they follow whatever kernels the plan chose (e.g. the one-launch feed-forward,
+        # which has no hidden-activation re-read to count); the analytic model above stays as the fallback and cross-check.
+        rec = {}
+        for kk in kernels:
+            r = rec.setdefault(kk["family"], dict(bytes=0.0, flops=0.0, launches=0.0))
+            r["bytes"] += kk["algorithmic_bytes_per_launch"] * kk["launches_per_step"]
+            r["flops"] += kk["flops_per_launch"] * kk["launches_per_step"]
+            r["launches"] += kk["launches_per_step"]
+        for f in work:
+            if f in rec and rec[f]["bytes"] > 0:
+                work[f] = dict(bytes=rec[f]["bytes"], flops=rec[f]["flops"], launches=int(round(rec[f]["launches"])), model_bytes=work[f]["bytes"])
         dom = max(work, key=lambda f: per_step[f])
         w = work[dom]
         dur_ms = per_step[dom]

@@ -126,7 +126,7 @@ int iq_gemm_bf16_lnbwd(const void* A, int lda, const void* Wt, int ldw, const vo
  *        backward kernel's own wave / chunk / lane order (an opaque buffer between the two calls)
  *   dX1 = gH * W1t^T + residual (rounded to bf16), then exactly iq_ln_bwd on it with z1 / mean / rstd / gamma:
  *   dz bf16 [M,D], dy = dropout_mask(dz) * scale (only when drop->p > 0), partial: iq_ffn_chain_bwd_partial_rows(M) rows of
- *   [2*D] fp32 (dgamma | dbeta partial sums, one row per 32 data rows) for the fused fixed-order reduction (iq_reduce_seg_t).
+ *   [2*D] fp32 (dgamma | dbeta partial sums, one row per workgroup) for the fused fixed-order reduction (iq_reduce_seg_t).
  * W2t [F, D] and W1t [D, F] are the TRANSPOSED weights (bf16 row-major), M = frames * S. */
 int iq_ffn_chain_supported(int S, int D, int F);
 int iq_ffn_chain_bwd_partial_rows(int M);

@@ -437,7 +437,8 @@ def test_ffn_chain_backward_equals_gate_gemm_then_dgrad_layernorm_backward(L, fr
     nan = float("nan")
     gH1 = torch.full((M, F), nan, dtype=torch.bfloat16, device=dev()); dz1 = torch.full_like(z, nan); dy1 = torch.zeros_like(z)
     rows = L.iq_ffn_chain_bwd_partial_rows(M)
-    assert rows == (M + 31) // 32
+    units = (M + 31) // 32
+    assert rows in ((units + 1) // 2, (units + 3) // 4, (units + 6) // 7)          # one row per workgroup of 2 | 4 | 7 waves
     part1 = torch.full((rows, 2 * D), nan, device=dev())
     N.check(L.iq_ffn_chain_bwd(dO.data_ptr(), W2t.data_ptr(), gate.data_ptr(), scale, gH1.data_ptr(), W1t.data_ptr(), R.data_ptr(), z.data_ptr(),
                                mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), C.byref(dr) if pdrop > 0 else None, dz1.data_ptr(),

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
 //     dX1[M,D] = gH * W1t[D,F]^T + R                                           fp32, rounded to bf16 as the unfused GEMM stored it
 //     then exactly iq_ln_bwd on it:  g = dX1 * gamma, xhat = (Z1 - mean) * rstd,
 //     dZ = rstd * (g - mean_D(g) - xhat * mean_D(g * xhat)),  dY = dropout1_mask(dZ) * scale,
-//     partial[wave] = sums over the wave's 32 rows of (dX1 * xhat | dX1)      fp32 [2 D]  (norm1's gamma / beta gradient partials)
+//     partial[workgroup] = sums over its rows of (dX1 * xhat | dX1)            fp32 [2 D]  (norm1's gamma / beta gradient partials)
 // replacing the gate data-gradient GEMM and the FFN1 data-gradient GEMM + LayerNorm backward (gemm_lnbwd.hip): gH no longer
 // makes the round trip through HBM between them.  Same structure as the forward kernel above: dO rows as register
 // fragments, the two transposed weights through the LDS ring, the gated tile handed to the second product in registers.
@@ -380,7 +380,7 @@ struct FfnChainBwdParams {
   const bf16* dO; const bf16* W2t; const bf16* W1t;     // [M,D], [F,D], [D,F]
   const uint32_t* gate; const bf16* R; const bf16* Z1;  // gate bits of the forward kernel, [M,D], [M,D]
   const float* mean; const float* rstd; const float* gamma;
-  bf16* gH; bf16* dZ; bf16* dY; float* partial;         // [M,F], [M,D], [M,D], [ceil(M/32)][2 D]
+  bf16* gH; bf16* dZ; bf16* dY; float* partial;         // [M,F], [M,D], [M,D], [workgroups][2 D]
   int M, F;
   float gate_scale;
   int drop_on; IqRng rng; uint32_t thresh; float dscale;
@@ -575,8 +575,6 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
     read_w2(std::integral_constant<int, 0>{}, wq[0]);
     p2(p2, std::integral_constant<int, 0>{});
   }
-  if (!have) return;
-
   // ---- tail: dX1 = acc2 + R, rounded to bf16 as the unfused data-gradient GEMM stored it, into a wave-private LDS image; then
   //      ln_bwd_kernel's own arithmetic on it in LayerNorm's layout (a row = 8 lanes x NV 16-byte vectors): the accumulators are
   //      released at once (doing the LayerNorm in the MFMA register layout -- 96 accumulators + the row's Z and dX -- spilled
@@ -591,6 +589,8 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
     const int per = SLOT / IMG;                         // whole images per slot
     img = reinterpret_cast<bf16*>(smem + (wave < per ? s2 * SLOT + wave * IMG : s3 * SLOT + (wave - per) * IMG));
   }
+  float* wsum = reinterpret_cast<float*>(img);          // [2 D]: this wave's column sums, parked over its (then dead) image
+  if (have) {
 #pragma unroll
   for (int rg = 0; rg < 2; ++rg) {
     const long gr = min(row0 + rg * 16 + c16, (long)p.M - 1);
@@ -672,7 +672,8 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
       }
     }
     // column sums over the wave's 32 rows: lanes with the same lj hold the same columns (8 row slots): fixed-order shuffles
-    float* prow = p.partial + (row0 / 32) * (2 * D);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the image has been read: the sums may overwrite its head)
+    float* prow = wsum;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
 #pragma unroll
@@ -689,6 +690,23 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
         *reinterpret_cast<f32x4*>(prow + D + c) = f32x4{ab[v][0], ab[v][1], ab[v][2], ab[v][3]};
         *reinterpret_cast<f32x4*>(prow + D + c + 4) = f32x4{ab[v][4], ab[v][5], ab[v][6], ab[v][7]};
       }
+    }
+  }
+  } else {
+    for (int i = lane; i < 2 * D; i += 64) wsum[i] = 0.f;           // a wave without rows contributes zeros
+  }
+  // one partial row per WORKGROUP: the waves' sums added in wave order (fixed: reproducible) -- seven times fewer rows for the
+  // layer's slab reduce than one per wave
+  __syncthreads();
+  {
+    constexpr int per = SLOT / IMG;
+    const int s2 = (nchunk >= 2 ? nchunk - 2 : 1) % FC_NS, s3 = (nchunk >= 2 ? nchunk : 2) % FC_NS;
+    for (int i = tid; i < 2 * D; i += NW * 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+        t += reinterpret_cast<const float*>(smem + (w < per ? s2 * SLOT + w * IMG : s3 * SLOT + (w - per) * IMG))[i];
+      p.partial[(long)blockIdx.x * (2 * D) + i] = t;
     }
   }
 }
@@ -800,7 +818,11 @@ extern "C" int iq_ffn_chain_fwd(const void* X1, const void* W1, const float* b1,
   return D == 192 ? launch_chain_d<192>(p, st) : launch_chain_d<128>(p, st);
 }
 
-extern "C" int iq_ffn_chain_bwd_partial_rows(int M) { return M > 0 ? (M + 31) / 32 : 0; }
+extern "C" int iq_ffn_chain_bwd_partial_rows(int M) {      // one per workgroup
+  if (M <= 0) return 0;
+  const int nw = chain_waves(M);
+  return (int)((((long)M + 31) / 32 + nw - 1) / nw);
+}
 
 extern "C" size_t iq_ffn_chain_gate_bytes(int M, int F) {
   if (M <= 0 || F <= 0) return 0;

@@ -521,11 +521,9 @@ unsigned long long* g_wstamps = nullptr;
 int launch_reduce(const RedGroup& rg, int nblk, hipStream_t st) {
   IQ_PROF(IQ_FAM_WGRAD, st);
   wgrad_reduce_kernel<<<nblk, 256, 0, st>>>(rg);
-  if (iq_prof_scope_.on) {
-    double bytes = 0;
-    for (int i = 0; i < rg.nseg; ++i) bytes += 4.0 * rg.s[i].n * (rg.s[i].rows + 1 + (rg.accumulate ? 1 : 0));
-    IQ_PROF_K(bytes, 0.0, "wgrad_reduce_kernel");
-  }
+  // (no algorithmic bytes of its own: the gradient it writes is counted with the partial-tile kernel; its slab traffic exists
+  //  because of the M-split and shows up as this launch's time)
+  IQ_PROF_K(0.0, 0.0, "wgrad_reduce_kernel");
   return IQ_OK;
 }
 
