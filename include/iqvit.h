@@ -109,15 +109,24 @@ int iq_gemm_bf16_lnbwd(const void* A, int lda, const void* Wt, int ldw, const vo
                        const float* mean, const float* rstd, const float* gamma, const iq_dropout_t* drop, void* dz,
                        void* dy, float* partial, int M, int D, int K, iq_stream_t stream);
 
-/* The feed-forward sub-layer of whole FRAMES in one launch (one workgroup per frame of S rows, D in {128, 192},
- * F % 128 == 0, S <= 224):
- *   H = dropout1(relu(X1 * W1^T + b1))            bf16 [frames*S, F]  (written once; backward reads it)
- *   Z = dropout2(H * W2^T + b2) + X1              bf16 [frames*S, D]  (kept for backward)
- *   X = gamma * (Z - mean) * rstd + beta          bf16 [frames*S, D];  mean, rstd fp32 [frames*S]
+/* The feed-forward sub-layer + norm2 in one launch (rows are owned by waves, 32 at a time; M = frames * S rows, D in {128, 192},
+ * F % 64 == 0, the LDS weight ring + F floats within 160 KB: iq_ffn_chain_supported):
+ *   H = dropout1(relu(X1 * W1^T + b1))            bf16 [M, F]  (written once; the weight gradients read it)
+ *   Z = dropout2(H * W2^T + b2) + X1              bf16 [M, D]  (kept for backward)
+ *   X = gamma * (Z - mean) * rstd + beta          bf16 [M, D];  mean, rstd fp32 [M]
  * = PositionwiseFeedForward.forward (V/models/layers/position_wise_feed_forward.py:12-17) + `x = norm2(dropout2(ffn(x)) + x)`
- * (V/models/blocks/encoder_layer.py:30-33).  H is consumed from LDS, never re-read from HBM.  H and Z are bit-identical to
- * iq_gemm_bf16_nt (bias, relu, drop1) followed by iq_gemm_bf16_ln; dropout indices as there (output element row*N + n).
- * W1 [F, D], W2 [D, F] bf16 row-major; all pointers 16-byte aligned. */
+ * (V/models/blocks/encoder_layer.py:30-33).  The hidden tile goes from the first product's epilogue into the second product in
+ * registers, never re-read from HBM.  H and Z equal iq_gemm_bf16_nt (bias, relu, drop1) followed by iq_gemm_bf16_ln up to fp32
+ * summation order inside one MFMA (bf16 rounding ties only); dropout indices as there (output element row*N + n).
+ * W1 [F, D], W2 [D, F] bf16 row-major; all pointers 16-byte aligned.
+ * iq_attn_out_ffn_chain_fwd: the same launch with the attention output projection + dropout + residual + norm1 in front
+ * (`x = norm1(dropout1(attention_out) + x)`, encoder_layer.py:24-28 -- the whole layer after the attention core):
+ *   Z1 = dropout0(A * Wo^T + bo) + R              bf16 [M, D]  (kept for backward)
+ *   X1 = gamma1 * (Z1 - mean1) * rstd1 + beta1    bf16 [M, D] (written for backward; consumed from registers);  mean1, rstd1 [M]
+ * then as above on X1.  A [M, D] attention output, Wo [D, D], R [M, D] the layer input.  Z1 equals iq_gemm_bf16_ln's up to bf16
+ * rounding ties (summation order inside one MFMA); the rest equals iq_ffn_chain_fwd on the X1 written, bit for bit.
+ * Wq / bq / Yq (all three or none): Yq[M, 3D] = X * Wq[3D, D]^T + bq behind norm2 -- the NEXT layer's packed q,k,v projection
+ * (multi_head_attention.py:17-19) of this layer's output, from registers. */
 /* iq_ffn_chain_bwd: the data path of the same sub-layer's backward in one launch (replaces the gate data-gradient GEMM and
  * iq_gemm_bf16_lnbwd; autograd of position_wise_feed_forward.py:12-17 and of the norm1 feeding it, encoder_layer.py:24-25):
  *   gH = (H > 0) ? (dO * W2t^T) * gate_scale : 0         bf16 [M,F]   (written once: the W1 / W2 weight gradients read it)
@@ -138,6 +147,12 @@ int iq_ffn_chain_bwd(const void* dO, const void* W2t, const void* gate_bits, flo
 int iq_ffn_chain_fwd(const void* X1, const void* W1, const float* b1, const iq_dropout_t* drop1, void* H, const void* W2,
                      const float* b2, const iq_dropout_t* drop2, const float* gamma, const float* beta, float eps, void* Z,
                      void* X, float* mean, float* rstd, void* gate_bits, int frames, int S, int D, int F, iq_stream_t stream);
+int iq_attn_out_ffn_chain_fwd(const void* A, const void* Wo, const float* bo, const iq_dropout_t* drop0, const void* R,
+                              const float* gamma1, const float* beta1, void* Z1, void* X1, float* mean1, float* rstd1,
+                              const void* W1, const float* b1, const iq_dropout_t* drop1, void* H, const void* W2, const float* b2,
+                              const iq_dropout_t* drop2, const float* gamma2, const float* beta2, float eps, void* Z2, void* X,
+                              float* mean2, float* rstd2, void* gate_bits, const void* Wq, const float* bq, void* Yq, int frames,
+                              int S, int D, int F, iq_stream_t stream);
 
 /* Weight gradient: dW[N,K] (+)= dY[M,N]^T * X[M,K]; dbias[N] (+)= colsum(dY) (NULL to skip).
  * Split over M into slabs in `ws` (iq_wgrad_ws_bytes), reduced deterministically (no atomics). */

@@ -89,6 +89,23 @@ def ffn_chain():
                                            W2.data_ptr(), b2.data_ptr(), C.byref(d2) if drop > 0 else None, gm.data_ptr(), bt.data_ptr(), 1e-12,
                                            Z.data_ptr(), X.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None, B, S, D, F, st()))
     print(f"{'[ffn chain: ffn1 + ffn2 + norm2]':34s} {us:8.1f} us  {(2 * (3 * M * D + M * F + 2 * D * F)) / us / 1e3:8.1f} GB/s  {4 * M * D * F / us / 1e6:8.1f} TFLOP/s", flush=True)
+    A = bf(M, D); R = bf(M, D); Wo = (torch.randn(D, D, device=d) / math.sqrt(D)).bfloat16(); bo = torch.randn(D, device=d)
+    Z1 = torch.empty_like(Z); m1 = torch.empty(M, device=d); r1 = torch.empty(M, device=d); d0 = dr(1)
+    gate = torch.empty(L.iq_ffn_chain_gate_bytes(M, F) // 4, dtype=torch.int32, device=d)
+    dp = lambda x: C.byref(x) if drop > 0 else None
+    us = timeit(lambda: L.iq_attn_out_ffn_chain_fwd(A.data_ptr(), Wo.data_ptr(), bo.data_ptr(), dp(d0), R.data_ptr(), gm.data_ptr(), bt.data_ptr(),
+                                                    Z1.data_ptr(), X1.data_ptr(), m1.data_ptr(), r1.data_ptr(), W1.data_ptr(), b1.data_ptr(), dp(d1),
+                                                    Hh.data_ptr(), W2.data_ptr(), b2.data_ptr(), dp(d2), gm.data_ptr(), bt.data_ptr(), 1e-12,
+                                                    Z.data_ptr(), X.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gate.data_ptr(), None, None, None,
+                                                    B, S, D, F, st()))
+    print(f"{'[out-proj + norm1 + ffn chain]':34s} {us:8.1f} us  (gate bits written)", flush=True)
+    Wq = (torch.randn(3 * D, D, device=d) / math.sqrt(D)).bfloat16(); bq = torch.randn(3 * D, device=d); Yq = torch.empty(M, 3 * D, device=d, dtype=torch.bfloat16)
+    us = timeit(lambda: L.iq_attn_out_ffn_chain_fwd(A.data_ptr(), Wo.data_ptr(), bo.data_ptr(), dp(d0), R.data_ptr(), gm.data_ptr(), bt.data_ptr(),
+                                                    Z1.data_ptr(), X1.data_ptr(), m1.data_ptr(), r1.data_ptr(), W1.data_ptr(), b1.data_ptr(), dp(d1),
+                                                    Hh.data_ptr(), W2.data_ptr(), b2.data_ptr(), dp(d2), gm.data_ptr(), bt.data_ptr(), 1e-12,
+                                                    Z.data_ptr(), X.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gate.data_ptr(), Wq.data_ptr(),
+                                                    bq.data_ptr(), Yq.data_ptr(), B, S, D, F, st()))
+    print(f"{'[... + next q,k,v]':34s} {us:8.1f} us", flush=True)
 print(f"D={D} H={H} F={F} S={S} B={B} M={M} drop={drop}")
 nt("qkv projection", 3 * D, D, bias=True)
 tb = attn()

@@ -2,8 +2,8 @@
 # PMC passes over whole training steps (eager launches), one rocprofv3 run per counter set (guide: FETCH_SIZE and WRITE_SIZE
 # do not fit one pass; no trace domain other than --kernel-trace next to --pmc).
 #   scripts/pmc_family.sh <config B|C|...> <out.json>
-# Per kernel family: HBM-side bytes per launch (FETCH_SIZE x2: gfx950 counts 64 B per 128 B request, MI355X_MICROARCH.md
-# "HBM"; WRITE_SIZE as is).  Whole step: MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8).
+# Per kernel family: fabric-side bytes per launch -- what the L2s fetched from / wrote to the memory fabric, i.e. HBM or the
+# Infinity Cache in front of it (FETCH_SIZE x2: gfx950 counts 64 B per 128 B request, MI355X_MICROARCH.md "HBM"; WRITE_SIZE as is).  Whole step: MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8).
 cfg=${1:-B}; out=${2:-gpurun_out/pmc_family_cfg$cfg.json}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 i=0
@@ -15,10 +15,10 @@ python3 - "$cfg" "$out" <<'PY'
 import csv, glob, json, collections, sys
 cfg, out_path = sys.argv[1], sys.argv[2]
 def fam_of(k):
-    if "gemm_nt" in k or "gemm_ln" in k or "gemm_chain" in k or "gemm_big" in k: return "gemm_nt"
+    if "gemm_nt" in k or "gemm_ln" in k or "ffn_chain" in k or "gemm_big" in k: return "gemm_nt"
     if "wgrad" in k: return "wgrad"
-    if "attn_bwd" in k: return "attn_bwd"
-    if "attn_fwd" in k: return "attn_fwd"
+    if "attn_bwd" in k or "attn_frame_bwd" in k: return "attn_bwd"
+    if "attn_fwd" in k or "attn_frame_fwd" in k: return "attn_fwd"
     if "ln_bwd" in k: return "ln_bwd"
     if "ln_fwd" in k: return "ln_fwd"
     return "misc"

@@ -394,6 +394,81 @@ def test_ffn_chain_equals_ffn1_then_ffn2_layernorm(L, frames, S, D, F, pdrop):
         close_bf16(X2, gamma.double() * ((zb - mu) / torch.sqrt(var + 1e-12)) + beta.double(), "X vs fp64")
 
 
+@pytest.mark.parametrize("with_qkv", [False, True])
+@pytest.mark.parametrize("frames,S,D,F,pdrop", [(256, 197, 192, 768, 0.1), (7, 197, 192, 832, 0.0), (256, 65, 128, 1024, 0.2),
+                                                 (5, 5, 128, 512, 0.0), (40, 197, 192, 64, 0.1), (2, 1, 192, 256, 0.0),
+                                                 (130, 65, 128, 128, 0.1)])
+def test_attn_out_ffn_chain_equals_gemm_ln_then_ffn_chain(L, frames, S, D, F, pdrop, with_qkv):
+    """iq_attn_out_ffn_chain_fwd (encoder_layer.py:24-33 from the attention output on, one launch) against the two launches it
+    replaces: its first stage (output projection + dropout + residual + norm1) against iq_gemm_bf16_ln -- equal except at
+    rounding ties (k-values enter the MFMAs in another lane-group order), same dropout mask -- its second stage bit for bit
+    against iq_ffn_chain_fwd run on the X1 it wrote, and (with_qkv) the next layer's packed q,k,v projection of its output
+    (multi_head_attention.py:17-19) against iq_gemm_bf16_nt on the X it wrote."""
+    N = _N()
+    M = frames * S
+    g = torch.Generator(device="cuda").manual_seed(M + D + F + 1)
+    A = bf(torch.randn(M, D, device=dev(), generator=g))
+    R = bf(torch.randn(M, D, device=dev(), generator=g))
+    Wo = bf(torch.randn(D, D, device=dev(), generator=g) / math.sqrt(D))
+    W1 = bf(torch.randn(F, D, device=dev(), generator=g) / math.sqrt(D))
+    W2 = bf(torch.randn(D, F, device=dev(), generator=g) / math.sqrt(F))
+    bo, b1, b2 = (torch.randn(n, device=dev(), generator=g) for n in (D, F, D))
+    g1, g2 = (torch.rand(D, device=dev(), generator=g) + 0.5 for _ in range(2))
+    be1, be2 = (torch.randn(D, device=dev(), generator=g) for _ in range(2))
+    d0, d1, d2 = _drop(78, 2, 4, pdrop), _drop(78, 2, 5, pdrop), _drop(78, 2, 6, pdrop)
+    dp = lambda d: C.byref(d) if pdrop > 0 else None
+    nan = float("nan")
+    new = lambda *shape, dt=torch.bfloat16: torch.full(shape, nan, dtype=dt, device=dev())
+    # reference first stage
+    Z1r, X1r, m1r, r1r = new(M, D), new(M, D), new(M, dt=torch.float32), new(M, dt=torch.float32)
+    N.check(L.iq_gemm_bf16_ln(A.data_ptr(), D, Wo.data_ptr(), D, bo.data_ptr(), R.data_ptr(), D, dp(d0), g1.data_ptr(), be1.data_ptr(),
+                              1e-12, Z1r.data_ptr(), X1r.data_ptr(), m1r.data_ptr(), r1r.data_ptr(), M, D, D, stream()), "gemm_ln")
+    # one launch
+    Z1, X1, m1, r1 = new(M, D), new(M, D), new(M, dt=torch.float32), new(M, dt=torch.float32)
+    H, Z2, X, m2, r2 = new(M, F), new(M, D), new(M, D), new(M, dt=torch.float32), new(M, dt=torch.float32)
+    gate = torch.zeros(L.iq_ffn_chain_gate_bytes(M, F) // 4, dtype=torch.int32, device=dev())
+    Wq = bf(torch.randn(3 * D, D, device=dev(), generator=g) / math.sqrt(D))
+    bq = torch.randn(3 * D, device=dev(), generator=g)
+    Yq = new(M, 3 * D)
+    qkv = (Wq.data_ptr(), bq.data_ptr(), Yq.data_ptr()) if with_qkv else (None, None, None)
+    N.check(L.iq_attn_out_ffn_chain_fwd(A.data_ptr(), Wo.data_ptr(), bo.data_ptr(), dp(d0), R.data_ptr(), g1.data_ptr(), be1.data_ptr(),
+                                        Z1.data_ptr(), X1.data_ptr(), m1.data_ptr(), r1.data_ptr(), W1.data_ptr(), b1.data_ptr(), dp(d1),
+                                        H.data_ptr(), W2.data_ptr(), b2.data_ptr(), dp(d2), g2.data_ptr(), be2.data_ptr(), 1e-12,
+                                        Z2.data_ptr(), X.data_ptr(), m2.data_ptr(), r2.data_ptr(), gate.data_ptr(), *qkv, frames, S, D, F,
+                                        stream()), "attn_out_ffn_chain")
+    for t in (Z1, X1, m1, r1, H, Z2, X, m2, r2) + ((Yq,) if with_qkv else ()):
+        assert torch.isfinite(t.float()).all()
+    if with_qkv:       # the next layer's q,k,v of the X written: iq_gemm_bf16_nt's result up to rounding ties
+        Yr = run_gemm(L, X, Wq, M, 3 * D, D, bias=bq)
+        neq = Yq.view(torch.int16) != Yr.view(torch.int16)
+        assert neq.float().mean().item() <= 2e-3, neq.float().mean().item()
+        exq = (Yq.float() - Yr.float()).abs() - (torch.maximum(Yq.float().abs(), Yr.float().abs()) * 2 ** -7 + 1e-5)
+        assert exq.max().item() <= 0.0, exq.max().item()
+        close_bf16(Yq, X.double() @ Wq.double().t() + bq.double(), "q,k,v vs fp64")
+    ne = Z1.view(torch.int16) != Z1r.view(torch.int16)
+    assert ne.float().mean().item() <= 2e-3, ne.float().mean().item()
+    excess = (Z1.float() - Z1r.float()).abs() - (torch.maximum(Z1.float().abs(), Z1r.float().abs()) * 2 ** -7 + 1e-5)
+    assert excess.max().item() <= 0.0, excess.max().item()
+    same = ~ne.any(1)
+    assert same.float().mean().item() > 0.7
+    assert torch.allclose(m1[same], m1r[same], rtol=0, atol=2e-6 * (m1r.abs().max().item() + 1))
+    assert torch.allclose(r1[same], r1r[same], rtol=2e-6, atol=0)
+    ulp = (X1.float() - X1r.float()).abs()[same] / (X1r.float().abs()[same] * 2 ** -7 + 1e-6)
+    assert ulp.max().item() <= 1.0 + 1e-3, ulp.max().item()
+    if pdrop > 0:      # the dropout mask of the projection output: zeros of (Z1 - R) coincide
+        assert (((Z1.float() - R.float()) == 0) == ((Z1r.float() - R.float()) == 0)).float().mean().item() > 1 - 1e-3
+    # second stage on the X1 the fused launch wrote: identical code path, identical bits
+    H2, Z22, X2, m22, r22 = new(M, F), new(M, D), new(M, D), new(M, dt=torch.float32), new(M, dt=torch.float32)
+    gate2 = torch.zeros_like(gate)
+    N.check(L.iq_ffn_chain_fwd(X1.data_ptr(), W1.data_ptr(), b1.data_ptr(), dp(d1), H2.data_ptr(), W2.data_ptr(), b2.data_ptr(), dp(d2),
+                               g2.data_ptr(), be2.data_ptr(), 1e-12, Z22.data_ptr(), X2.data_ptr(), m22.data_ptr(), r22.data_ptr(),
+                               gate2.data_ptr(), frames, S, D, F, stream()), "ffn_chain")
+    assert torch.equal(H.view(torch.int16), H2.view(torch.int16)) and torch.equal(Z2.view(torch.int16), Z22.view(torch.int16))
+    assert torch.equal(X.view(torch.int16), X2.view(torch.int16)) and torch.equal(m2, m22) and torch.equal(r2, r22)
+    full = (M // 32) * (F // 64) * 64                  # (bits of rows past M, in the last wave's ragged unit, are never read)
+    assert torch.equal(gate[:full], gate2[:full])
+
+
 @pytest.mark.parametrize("frames,S,D,F,pdrop", [(256, 197, 192, 768, 0.1), (7, 197, 192, 832, 0.0), (256, 65, 128, 1024, 0.2),
                                                  (5, 5, 128, 512, 0.0), (3, 224, 192, 128, 0.3), (9, 17, 128, 896, 0.1),
                                                  (40, 197, 192, 64, 0.1), (2, 1, 192, 256, 0.0)])

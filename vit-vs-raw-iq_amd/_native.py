@@ -68,6 +68,9 @@ SIGNATURES = {
     "iq_ffn_chain_gate_bytes": (_Z, [_I, _I]),
     "iq_ffn_chain_fwd": (_I, [_P, _P, _P, C.POINTER(Dropout), _P, _P, _P, C.POINTER(Dropout), _P, _P, _F, _P, _P, _P, _P, _P, _I, _I,
                               _I, _I, _P]),
+    "iq_attn_out_ffn_chain_fwd": (_I, [_P, _P, _P, C.POINTER(Dropout), _P, _P, _P, _P, _P, _P, _P,
+                                       _P, _P, C.POINTER(Dropout), _P, _P, _P, C.POINTER(Dropout), _P, _P, _F, _P, _P, _P, _P, _P,
+                                       _P, _P, _P, _I, _I, _I, _I, _P]),
     "iq_wgrad_ws_bytes": (_Z, [_I, _I, _I]),
     "iq_gemm_bf16_wgrad": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _Z, _I, _P]),
     "iq_wgrad_grouped_ws_bytes": (_Z, [_P, _I, _I, _I]),

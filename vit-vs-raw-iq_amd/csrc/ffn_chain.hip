@@ -52,6 +52,13 @@ struct FfnChainParams {
   int M, F;
   float eps;
   int drop1_on, drop2_on; IqRng rng1, rng2; uint32_t thresh1, thresh2; float dscale1, dscale2;
+  // optional first stage (PRE): X1 = norm1(dropout0(A0 * W0[D,D]^T + b0) + R0) is computed here (and written, with Z0 / mean0 /
+  // rstd0, for the backward pass) instead of read
+  const bf16* A0; const bf16* W0; const bf16* R0; const float* b0; const float* gamma0; const float* beta0;
+  bf16* Z0; bf16* X1out; float* mean0; float* rstd0;
+  int drop0_on; IqRng rng0; uint32_t thresh0; float dscale0;
+  // optional last stage (POST): Yq[M,3D] = X * Wq[3D,D]^T + bq -- the NEXT layer's packed q,k,v projection of this layer's output
+  const bf16* Wq; const float* bq; bf16* Yq;
 };
 
 // W1 image rows are D * 2 bytes (24 | 16 chunks of 16 B), W2 image rows 128 B (8 chunks).  Swizzles (involutions on the chunk
@@ -81,8 +88,17 @@ __device__ __forceinline__ int fc_kperm(int g) { return ((g & 1) << 1) | (g >> 1
 // NW = waves per workgroup (compile time: the ring's counted waits need the number of DMA pieces per wave), DROP1 = dropout
 // on the hidden activation (its Philox rounds are the kernel's largest block of vector work; computing a chunk's keep flags
 // one chunk ahead, beside the second product's MFMAs, measured slower: 71.8 vs 65.9 us).
-template <int D, int NW, bool DROP1>
+// PRE = the attention output projection + dropout + residual + norm1 (EncoderLayer.forward, encoder_layer.py:24-28) in front: the
+// projection is one more "first product" (K = D, W0's rows in 64-row blocks through the LDS ring region before the FFN weights
+// need it), and after the permlane swap its output tile is, lane for lane, the activation fragment of the FFN's first product:
+// norm1's output never leaves the registers on its way into the FFN.
+// POST = the NEXT layer's q,k,v projection (scale_dot_product_attention's inputs, multi_head_attention.py:17-19) behind norm2:
+// its weight's 64-row blocks are further ring "chunks" (two blocks fill one slot exactly), norm2's output tile is their activation
+// fragment, the tail runs between the last FFN chunk and the first of them while they are already in flight.
+// MODE 0: the feed-forward sub-layer alone; 1: PRE; 2: PRE and POST.
+template <int D, int NW, bool DROP1, int MODE>
 __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChainParams p) {
+  constexpr bool PRE = MODE >= 1, POST = MODE == 2;
   constexpr int XCPR = D / 8;                           // 16-byte chunks per W1 image row
   constexpr int KS1 = D / 32;                           // k-steps of the first product: 6 | 4
   constexpr int NT2 = D / 16, NP2 = NT2 / 2;            // output column tiles / pairs: 12, 6 | 8, 4
@@ -109,10 +125,12 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
     unsigned char* slot = smem + (c % FC_NS) * SLOT;
     const char* base1 = reinterpret_cast<const char*>(p.W1 + (long)c * FC_CHUNK * D);
     const char* base2 = reinterpret_cast<const char*>(p.W2 + (long)c * FC_CHUNK);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                        // (keeps the offsets below from being hoisted out of the chunk loop)
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int pc = min(wave + i * NW, PIECES - 1);    // wave-uniform
-      const int lin = pc * 64 + lane;
+      const int lin = pc * 64 + ln;
       unsigned off;
       if (pc < W1_PIECES) {                             // W1 rows f0 .. f0 + 63, all D columns
         const int r = lin / XCPR, sl = lin - r * XCPR;
@@ -128,24 +146,88 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
       __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(base + off), (lds_void_t*)(slot + pc * 1024), 16, 0, 0);
     }
   };
+  // POST: q,k,v weight rows 128 q .. 128 q + 127 as two W1-type images (one slot); rows past 3 D (the last, half chunk) repeat the
+  // last row (never read)
+  constexpr int NBQ = 3 * D / FC_CHUNK, NQ = (NBQ + 1) / 2;      // 9 blocks in 5 chunks | 6 in 3
+  static_assert(2 * W1_BYTES == SLOT, "two projection blocks fill a ring slot");
+  const int ntot = nchunk + (POST ? NQ : 0);
+  auto issue_any = [&](int c) {
+    if (!POST || c < nchunk) { issue_chunk(c); return; }
+    const int q = c - nchunk;
+    unsigned char* slot = smem + (c % FC_NS) * SLOT;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                        // (not loop-invariant as far as the compiler knows: see issue_chunk)
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = min(wave + i * NW, PIECES - 1);
+      const int lin = pc * 64 + ln;
+      const int r = lin / XCPR, sl = lin - r * XCPR;
+      const int qq = fc_swz<XCPR>(r & 63, sl);
+      const int grow = min(q * 2 * FC_CHUNK + r, 3 * D - 1);
+      const unsigned off = (unsigned)((grow * D + ((qq & ~3) | fc_kperm(qq & 3)) * 8) * 2);
+      __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(reinterpret_cast<const char*>(p.Wq) + off), (lds_void_t*)(slot + pc * 1024), 16, 0, 0);
+    }
+  };
+  // PRE: W0's NB0 row blocks (W1-type images, contiguous from ring slot 1 on: 73,728 of 98,304 | 32,768 of 32,768 bytes); the
+  // FFN's chunk 0 travels beside them into slot 0, chunk 1 follows once the projection has been consumed
+  constexpr int NB0 = D / FC_CHUNK;
+  if (PRE) {
+    constexpr int PRE_PIECES = NB0 * W1_PIECES, PRE_PPW = (PRE_PIECES + NW - 1) / NW;
+    static_assert(NB0 * W1_BYTES <= 2 * SLOT, "projection weight blocks fit ring slots 1 and 2");
+#pragma unroll
+    for (int i = 0; i < PRE_PPW; ++i) {
+      const int pc = min(wave + i * NW, PRE_PIECES - 1);
+      const int lin = pc * 64 + lane;                   // (blocks are contiguous in both the image and, row-wise, in W0)
+      const int r = lin / XCPR, sl = lin - r * XCPR;
+      const int q = fc_swz<XCPR>(r & 63, sl);
+      const unsigned off = (unsigned)((r * D + ((q & ~3) | fc_kperm(q & 3)) * 8) * 2);
+      __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(reinterpret_cast<const char*>(p.W0) + off),
+                                       (lds_void_t*)(smem + SLOT + pc * 1024), 16, 0, 0);
+    }
+  }
   issue_chunk(0);
-  if (nchunk > 1) issue_chunk(1);
+  if (!PRE && ntot > 1) issue_any(1);
 
   // ---- this wave's X1 rows as activation fragments: xf[rg][ks] = row 16 rg + c16, columns 32 ks + 8 kperm(g) .. +7 ----------
+  // (PRE: the attention output's rows first -- the projection's activation fragments -- then norm1's output in the same registers)
   bf16x8 xf[2][KS1];
+  {
+    const bf16* src = PRE ? p.A0 : p.X1;
 #pragma unroll
-  for (int rg = 0; rg < 2; ++rg) {
-    const long r = min(row0 + rg * 16 + c16, (long)p.M - 1);
+    for (int rg = 0; rg < 2; ++rg) {
+      const long r = min(row0 + rg * 16 + c16, (long)p.M - 1);
 #pragma unroll
-    for (int ks = 0; ks < KS1; ++ks)
-      xf[rg][ks] = have ? *reinterpret_cast<const bf16x8*>(p.X1 + r * D + 32 * ks + 8 * fc_kperm(g)) : bf16x8{};
+      for (int ks = 0; ks < KS1; ++ks)
+        xf[rg][ks] = have ? *reinterpret_cast<const bf16x8*>(src + r * D + 32 * ks + 8 * fc_kperm(g)) : bf16x8{};
+    }
+  }
+  // PRE: the residual rows too, in the projection's output layout (pair jp: columns 32 jp + 8 kperm(g) .. +7, as xf) -- fetched per
+  // column pair inside the projection loop, each 200-cycle MFMA group waited for an HBM round trip (23 us for the stage)
+  bf16x8 res0[PRE ? 2 : 1][PRE ? KS1 : 1];
+  if (PRE) {
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg) {
+      const long r = min(row0 + rg * 16 + c16, (long)p.M - 1);
+#pragma unroll
+      for (int jp = 0; jp < KS1; ++jp)
+        res0[rg][jp] = have ? *reinterpret_cast<const bf16x8*>(p.R0 + r * D + 32 * jp + 8 * fc_kperm(g)) : bf16x8{};
+    }
   }
   const IqRng rng1 = DROP1 ? rng_resolve(p.rng1) : p.rng1;
   const IqRng rng2 = p.drop2_on ? rng_resolve(p.rng2) : p.rng2;
   // b1 lives in LDS behind the ring: a register-destination global load inside the chunk loop makes hipcc wait vmcnt(0) at
-  // its first use (cdna_hip_programming.md, "mixing load kinds in one k-loop"), i.e. for the ring pieces just requested
+  // its first use (cdna_hip_programming.md, "mixing load kinds in one k-loop"), i.e. for the ring pieces just requested.
+  // Behind it the per-column vectors of the tail (b2, gamma, beta) and of the first stage (b0, gamma0, beta0): [6][D] floats.
   float* b1s = reinterpret_cast<float*>(smem + FC_NS * SLOT);
+  float* vecs = b1s + F;
   for (int i = tid; i < F / 4; i += NW * 64) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
+  for (int i = tid; i < (PRE ? 6 : 3) * (D / 4); i += NW * 64) {
+    const int v = i / (D / 4), j = i - v * (D / 4);
+    const float* src = v == 0 ? p.b2 : v == 1 ? p.gamma : v == 2 ? p.beta : v == 3 ? p.b0 : v == 4 ? p.gamma0 : p.beta0;
+    reinterpret_cast<f32x4*>(vecs)[i] = reinterpret_cast<const f32x4*>(src)[j];
+  }
+  if (POST)                                             // bq [3 D] behind them
+    for (int i = tid; i < 3 * D / 4; i += NW * 64) reinterpret_cast<f32x4*>(vecs + 6 * D)[i] = reinterpret_cast<const f32x4*>(p.bq)[i];
   // Everything requested so far has landed (chunks 0 and 1 as well: they had the X1 round trip to travel); the X1 fragments
   // are then passed through an empty asm so that the compiler stops tracking them as results of pending loads -- it cannot
   // see across the loop's back edge and would otherwise wait vmcnt(0) before their first use in EVERY iteration.
@@ -154,21 +236,135 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
   for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) asm volatile("" : "+v"(xf[rg][ks]));
+  if (PRE) {
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+      for (int jp = 0; jp < KS1; ++jp) asm volatile("" : "+v"(res0[rg][jp]));
+  }
+
+  // slot-relative byte offsets of this lane's fragment reads: row c16 of a 16-row tile (tiles add a compile-time offset: the
+  // swizzle only looks at (row >> 1) & 7 = (c16 >> 1) & 7), k-step ks of the W1 image / jp of the W2 image
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  // (384-byte rows: the swizzle leaves the chunk's bits above 3 alone, k-step ks reads 128 (ks >> 1) bytes behind k-step ks & 1:
+  //  two resident offsets instead of six)
+  constexpr int W1_KMASK = XCPR == 24 ? 1 : KS1 - 1;
+  uint32_t w1off[KS1], w2off[2];
+  auto w1at = [&](int ks) -> uint32_t { return w1off[ks & W1_KMASK] + (XCPR == 24 ? 128u * (uint32_t)(ks >> 1) : 0u); };
+#pragma unroll
+  for (int ks = 0; ks < KS1; ++ks) w1off[ks] = (uint32_t)(c16 * (D * 2) + fc_swz<XCPR>(c16, 4 * (ks & W1_KMASK) + g) * 16);
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp) w2off[jp] = (uint32_t)(W1_BYTES + c16 * 128 + fc_swz<8>(c16, 4 * jp + g) * 16);
+
+  if (PRE) {
+    __syncthreads();                                    // every wave's pieces of W0 are in LDS
+    if (have) {
+      const IqRng rng0 = p.drop0_on ? rng_resolve(p.rng0) : p.rng0;
+      bf16x8 zb[2][KS1];                                // z0 = dropout0(A0 W0^T + b0) + R0, bf16 as stored, [rg][32-column pair]
+#pragma unroll
+      for (int b = 0; b < NB0; ++b) {
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          const int col = 32 * (2 * b + jp) + (odd ? 16 + 4 * (g - 1) : 4 * g);
+          f32x4 acc1[2][2];
+#pragma unroll
+          for (int rg = 0; rg < 2; ++rg) { acc1[rg][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+          bf16x8 wp[2][2];
+          const uint32_t blk = lds0 + SLOT + b * W1_BYTES;
+          auto read_w0 = [&](int ks, bf16x8 (&dst)[2]) {
+            const uint32_t a0 = blk + w1at(ks);
+            if (jp == 0) { lds_read128<0 * 16 * D * 2>(dst[0], a0); lds_read128<1 * 16 * D * 2>(dst[1], a0); }
+            else { lds_read128<2 * 16 * D * 2>(dst[0], a0); lds_read128<3 * 16 * D * 2>(dst[1], a0); }
+          };
+          read_w0(0, wp[0]);
+#pragma unroll
+          for (int ks = 0; ks < KS1; ++ks) {
+            if (ks + 1 < KS1) { read_w0(ks + 1, wp[(ks + 1) & 1]); FC_LGKM_WAIT(2); }
+            else FC_LGKM_WAIT(0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              acc1[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[0][ks], acc1[0][t], 0, 0, 0);
+              acc1[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[1][ks], acc1[1][t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          const f32x4 b_lo = *reinterpret_cast<const f32x4*>(vecs + 3 * D + col), b_hi = *reinterpret_cast<const f32x4*>(vecs + 3 * D + col + 4);
+#pragma unroll
+          for (int rg = 0; rg < 2; ++rg) {
+            float w[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float va = acc1[rg][0][r], vb = acc1[rg][1][r];
+              const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
+              w[r] = __uint_as_float(sw[0]) + b_lo[r];
+              w[4 + r] = __uint_as_float(sw[1]) + b_hi[r];
+            }
+            const long grow = row0 + rg * 16 + c16;
+            if (p.drop0_on) {
+              const uint32_t keep = dropout_keep8(rng0, (uint64_t)(grow * D + col) >> 3, p.thresh0);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) w[e] = ((keep >> e) & 1u) ? w[e] * p.dscale0 : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] += (float)res0[rg][2 * b + jp][e];
+            zb[rg][2 * b + jp] = pack8(w);
+            if (grow < p.M) *reinterpret_cast<bf16x8*>(p.Z0 + grow * D + col) = zb[rg][2 * b + jp];
+          }
+        }
+      }
+      // norm1 on the wave's own rows (two-pass on the bf16-rounded z0, as the tail below); its output is the FFN's fragment
+      const float invD0 = 1.0f / (float)D;
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg) {
+        const long grow = row0 + rg * 16 + c16;
+        float s1 = 0.f;
+#pragma unroll
+        for (int jp = 0; jp < KS1; ++jp)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s1 += (float)zb[rg][jp][e];
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        const float mean = s1 * invD0;
+        float s2 = 0.f;
+#pragma unroll
+        for (int jp = 0; jp < KS1; ++jp)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float d = (float)zb[rg][jp][e] - mean; s2 += d * d; }
+        s2 += __shfl_xor(s2, 16, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        const float rstd = 1.0f / sqrtf(s2 * invD0 + p.eps);
+        if (g == 0 && grow < p.M) { p.mean0[grow] = mean; p.rstd0[grow] = rstd; }
+#pragma unroll
+        for (int jp = 0; jp < KS1; ++jp) {
+          const int col = 32 * jp + (odd ? 16 + 4 * (g - 1) : 4 * g);
+          const f32x4 g_lo = *reinterpret_cast<const f32x4*>(vecs + 4 * D + col), g_hi = *reinterpret_cast<const f32x4*>(vecs + 4 * D + col + 4);
+          const f32x4 e_lo = *reinterpret_cast<const f32x4*>(vecs + 5 * D + col), e_hi = *reinterpret_cast<const f32x4*>(vecs + 5 * D + col + 4);
+          float y[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            y[e] = g_lo[e] * (((float)zb[rg][jp][e] - mean) * rstd) + e_lo[e];
+            y[4 + e] = g_hi[e] * (((float)zb[rg][jp][4 + e] - mean) * rstd) + e_hi[e];
+          }
+          xf[rg][jp] = pack8(y);
+          if (grow < p.M) *reinterpret_cast<bf16x8*>(p.X1out + grow * D + col) = xf[rg][jp];
+        }
+      }
+    }
+    // every wave is done with W0's image: the ring proper starts (the stage's stores stay in flight: they are OLDER than any
+    // ring piece requested from here on, the loop's counted waits retire them first)
+    __syncthreads();
+    if (ntot > 1) issue_any(1);
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) asm volatile("" : "+v"(xf[rg][ks]));
+  }
 
   f32x4 acc2[2][NT2];
 #pragma unroll
   for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
     for (int j = 0; j < NT2; ++j) acc2[rg][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // slot-relative byte offsets of this lane's fragment reads: row c16 of a 16-row tile (tiles add a compile-time offset: the
-  // swizzle only looks at (row >> 1) & 7 = (c16 >> 1) & 7), k-step ks of the W1 image / jp of the W2 image
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
-  uint32_t w1off[KS1], w2off[2];
-#pragma unroll
-  for (int ks = 0; ks < KS1; ++ks) w1off[ks] = (uint32_t)(c16 * (D * 2) + fc_swz<XCPR>(c16, 4 * ks + g) * 16);
-#pragma unroll
-  for (int jp = 0; jp < 2; ++jp) w2off[jp] = (uint32_t)(W1_BYTES + c16 * 128 + fc_swz<8>(c16, 4 * jp + g) * 16);
-
   // a wave whose 32 rows all exist stores exactly 4 H vectors per chunk: its ring waits can be COUNTED (the stores and the
   // next chunk's pieces stay in flight); a ragged wave waits for everything
   const bool full = row0 + 32 <= p.M;
@@ -186,13 +382,13 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
 #endif
     if (c == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (b1 image written; the ring's first chunks: above)
     else if (!full || nchunk < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (gated && c + 1 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW + 10) : "memory");
+    else if (gated && c + 1 < ntot) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW + 10) : "memory");
     else if (gated) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if (c + 1 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW + 8) : "memory");
+    else if (c + 1 < ntot) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW + 8) : "memory");
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (c + 2 < nchunk) issue_chunk(c + 2);
+    if (c + 2 < ntot) issue_any(c + 2);
 #ifdef FC_NO_RING
   ring_done:
 #endif
@@ -211,7 +407,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
 #pragma unroll
       for (int rg = 0; rg < 2; ++rg) { acc1[rg][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       auto read_w1 = [&](int ks, bf16x8 (&dst)[2]) {
-        const uint32_t a0 = slot_addr + w1off[ks];
+        const uint32_t a0 = slot_addr + w1at(ks);
         if (jp == 0) { lds_read128<0 * 16 * D * 2>(dst[0], a0); lds_read128<1 * 16 * D * 2>(dst[1], a0); }
         else { lds_read128<2 * 16 * D * 2>(dst[0], a0); lds_read128<3 * 16 * D * 2>(dst[1], a0); }
       };
@@ -296,11 +492,13 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
     read_w2(std::integral_constant<int, 0>{}, wq[0]);
     p2(p2, std::integral_constant<int, 0>{});
   }
-  if (!have) return;
+  if (!POST && !have) return;
 
   // ---- tail: z = dropout2(acc2 + b2) + x1 (bf16), LayerNorm over the wave's own rows -----------------------------------------
   // pair jp covers columns 32 jp .. 32 jp + 31; after the swap this lane holds columns 32 jp + 8 kperm(g) .. +7 -- exactly xf[rg][jp]
+  // (POST: norm2's output replaces x1 in xf -- the projection's activation fragments)
   const float invD = 1.0f / (float)D;
+  if (have) {
 #pragma unroll
   for (int rg = 0; rg < 2; ++rg) {
     const long grow = row0 + rg * 16 + c16;
@@ -309,7 +507,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
 #pragma unroll
     for (int jp = 0; jp < NP2; ++jp) {
       const int col = 32 * jp + (odd ? 16 + 4 * (g - 1) : 4 * g);
-      const f32x4 b_lo = *reinterpret_cast<const f32x4*>(p.b2 + col), b_hi = *reinterpret_cast<const f32x4*>(p.b2 + col + 4);
+      const f32x4 b_lo = *reinterpret_cast<const f32x4*>(vecs + col), b_hi = *reinterpret_cast<const f32x4*>(vecs + col + 4);
       float w[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -347,15 +545,78 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
 #pragma unroll
       for (int jp = 0; jp < NP2; ++jp) {
         const int col = 32 * jp + (odd ? 16 + 4 * (g - 1) : 4 * g);
-        const f32x4 g_lo = *reinterpret_cast<const f32x4*>(p.gamma + col), g_hi = *reinterpret_cast<const f32x4*>(p.gamma + col + 4);
-        const f32x4 e_lo = *reinterpret_cast<const f32x4*>(p.beta + col), e_hi = *reinterpret_cast<const f32x4*>(p.beta + col + 4);
+        const f32x4 g_lo = *reinterpret_cast<const f32x4*>(vecs + D + col), g_hi = *reinterpret_cast<const f32x4*>(vecs + D + col + 4);
+        const f32x4 e_lo = *reinterpret_cast<const f32x4*>(vecs + 2 * D + col), e_hi = *reinterpret_cast<const f32x4*>(vecs + 2 * D + col + 4);
         float y[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           y[e] = g_lo[e] * ((z[jp][e] - mean) * rstd) + e_lo[e];
           y[4 + e] = g_hi[e] * ((z[jp][4 + e] - mean) * rstd) + e_hi[e];
         }
-        *reinterpret_cast<bf16x8*>(p.X + grow * D + col) = pack8(y);
+        const bf16x8 yb = pack8(y);
+        *reinterpret_cast<bf16x8*>(p.X + grow * D + col) = yb;
+        if (POST) xf[rg][jp] = yb;
+      }
+    }
+  }
+  }
+  if (!POST) return;
+
+  // ---- POST: Yq = X Wq^T + bq, 64 output columns (one weight block) at a time, two blocks per ring chunk ------------------------
+  for (int q = 0; q < NQ; ++q) {
+    const int c = nchunk + q;
+    // q = 0 drains the tail's stores with the ring (chunks q = 0 and 1 have landed then); later: younger than chunk c's pieces are
+    // the 8 + 8 Yq stores of the last two iterations and the pieces of chunk c + 1
+    if (q == 0 || !full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (c + 1 < ntot) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW + 16) : "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (c + 2 < ntot) issue_any(c + 2);
+    if (!have) continue;
+    const uint32_t slot_addr = lds0 + (c % FC_NS) * SLOT;
+#pragma unroll
+    for (int bl = 0; bl < 2; ++bl) {
+      if (2 * q + bl >= NBQ) break;                     // (the last chunk of an odd block count is half empty)
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        f32x4 acc1[2][2];
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg) { acc1[rg][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        bf16x8 wp[2][2];
+        const uint32_t blk = slot_addr + bl * W1_BYTES;
+        auto read_wq = [&](int ks, bf16x8 (&dst)[2]) {
+          const uint32_t a0 = blk + w1at(ks);
+          if (jp == 0) { lds_read128<0 * 16 * D * 2>(dst[0], a0); lds_read128<1 * 16 * D * 2>(dst[1], a0); }
+          else { lds_read128<2 * 16 * D * 2>(dst[0], a0); lds_read128<3 * 16 * D * 2>(dst[1], a0); }
+        };
+        read_wq(0, wp[0]);
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+          if (ks + 1 < KS1) { read_wq(ks + 1, wp[(ks + 1) & 1]); FC_LGKM_WAIT(2); }
+          else FC_LGKM_WAIT(0);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            acc1[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[0][ks], acc1[0][t], 0, 0, 0);
+            acc1[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[1][ks], acc1[1][t], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const int col = FC_CHUNK * (2 * q + bl) + 32 * jp + (odd ? 16 + 4 * (g - 1) : 4 * g);
+        const f32x4 b_lo = *reinterpret_cast<const f32x4*>(vecs + 6 * D + col), b_hi = *reinterpret_cast<const f32x4*>(vecs + 6 * D + col + 4);
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg) {
+          float w[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float va = acc1[rg][0][r], vb = acc1[rg][1][r];
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
+            w[r] = __uint_as_float(sw[0]) + b_lo[r];
+            w[4 + r] = __uint_as_float(sw[1]) + b_hi[r];
+          }
+          const long grow = row0 + rg * 16 + c16;
+          if (grow < p.M) *reinterpret_cast<bf16x8*>(p.Yq + grow * (3 * D) + col) = pack8(w);
+        }
       }
     }
   }
@@ -469,9 +730,13 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
     for (int j = 0; j < NT2; ++j) acc2[rg][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // slot-relative byte offsets of this lane's fragment reads (as in the forward kernel)
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  // (384-byte rows: the swizzle leaves the chunk's bits above 3 alone, k-step ks reads 128 (ks >> 1) bytes behind k-step ks & 1:
+  //  two resident offsets instead of six)
+  constexpr int W1_KMASK = XCPR == 24 ? 1 : KS1 - 1;
   uint32_t w1off[KS1], w2off[2];
+  auto w1at = [&](int ks) -> uint32_t { return w1off[ks & W1_KMASK] + (XCPR == 24 ? 128u * (uint32_t)(ks >> 1) : 0u); };
 #pragma unroll
-  for (int ks = 0; ks < KS1; ++ks) w1off[ks] = (uint32_t)(c16 * (D * 2) + fc_swz<XCPR>(c16, 4 * ks + g) * 16);
+  for (int ks = 0; ks < KS1; ++ks) w1off[ks] = (uint32_t)(c16 * (D * 2) + fc_swz<XCPR>(c16, 4 * (ks & W1_KMASK) + g) * 16);
 #pragma unroll
   for (int jp = 0; jp < 2; ++jp) w2off[jp] = (uint32_t)(W1_BYTES + c16 * 128 + fc_swz<8>(c16, 4 * jp + g) * 16);
 
@@ -501,7 +766,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
 #pragma unroll
       for (int rg = 0; rg < 2; ++rg) { acc1[rg][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       auto read_w1 = [&](int ks, bf16x8 (&dst)[2]) {
-        const uint32_t a0 = slot_addr + w1off[ks];
+        const uint32_t a0 = slot_addr + w1at(ks);
         if (jp == 0) { lds_read128<0 * 16 * D * 2>(dst[0], a0); lds_read128<1 * 16 * D * 2>(dst[1], a0); }
         else { lds_read128<2 * 16 * D * 2>(dst[0], a0); lds_read128<3 * 16 * D * 2>(dst[1], a0); }
       };
@@ -722,18 +987,19 @@ inline int chain_waves(int M) {
 template <int D, int NW>
 int launch_chain(const FfnChainParams& p, hipStream_t st) {
   constexpr int SLOT = 2 * FC_CHUNK * D * 2;
-  const size_t lds = (size_t)FC_NS * SLOT + (size_t)p.F * sizeof(float);     // ring (147,456 | 98,304 B) + b1
+  const size_t lds = (size_t)FC_NS * SLOT + ((size_t)p.F + 9 * D) * sizeof(float);     // ring (147,456 | 98,304 B) + b1 + nine [D] vectors
   const long units = ((long)p.M + 31) / 32;
   const int grid = (int)((units + NW - 1) / NW);
-#define FC_LAUNCH(DROP_)                                                                                                      \
+#define FC_LAUNCH(DROP_, MODE_)                                                                                               \
   do {                                                                                                                        \
-    auto k = ffn_chain_fwd_kernel<D, NW, DROP_>;                                                                              \
+    auto k = ffn_chain_fwd_kernel<D, NW, DROP_, MODE_>;                                                                       \
     static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     (void)attr;                                                                                                               \
     k<<<grid, NW * 64, lds, st>>>(p);                                                                                         \
   } while (0)
-  if (p.drop1_on) FC_LAUNCH(true);
-  else FC_LAUNCH(false);
+  if (p.A0 && p.Wq) { if (p.drop1_on) FC_LAUNCH(true, 2); else FC_LAUNCH(false, 2); }
+  else if (p.A0) { if (p.drop1_on) FC_LAUNCH(true, 1); else FC_LAUNCH(false, 1); }
+  else { if (p.drop1_on) FC_LAUNCH(true, 0); else FC_LAUNCH(false, 0); }
 #undef FC_LAUNCH
   return iq_launch_status();
 }
@@ -778,13 +1044,19 @@ int launch_chain_bwd_d(const FfnChainBwdParams& p, hipStream_t st) {
 // D = 128 | 192, F a multiple of 64 (S: rows per frame -- any; rows are owned by waves, 32 at a time, regardless of frames)
 extern "C" int iq_ffn_chain_supported(int S, int D, int F) {
   if (!(D == 128 || D == 192) || F < FC_CHUNK || (F % FC_CHUNK) || S <= 0) return 0;
-  return (size_t)FC_NS * 2 * FC_CHUNK * D * 2 + (size_t)F * sizeof(float) <= (size_t)160 * 1024 ? 1 : 0;      // F <= 4096 at D = 192
+  return (size_t)FC_NS * 2 * FC_CHUNK * D * 2 + ((size_t)F + 9 * D) * sizeof(float) <= (size_t)160 * 1024 ? 1 : 0;      // F <= 2368 at D = 192
 }
 
-extern "C" int iq_ffn_chain_fwd(const void* X1, const void* W1, const float* b1, const iq_dropout_t* drop1, void* H,
-                                const void* W2, const float* b2, const iq_dropout_t* drop2, const float* gamma,
-                                const float* beta, float eps, void* Z, void* X, float* mean, float* rstd, void* gate_bits,
-                                int frames, int S, int D, int F, iq_stream_t stream) {
+namespace {
+struct ChainPre {                                        // the optional first stage's operands (iq_attn_out_ffn_chain_fwd)
+  const void* A0; const void* W0; const float* b0; const iq_dropout_t* drop0; const void* R0;
+  const float* gamma0; const float* beta0; void* Z0; float* mean0; float* rstd0;
+  const void* Wq; const float* bq; void* Yq;            // optional last stage (all three or none)
+};
+
+int chain_fwd(const ChainPre* pre, const void* X1, const void* W1, const float* b1, const iq_dropout_t* drop1, void* H, const void* W2,
+              const float* b2, const iq_dropout_t* drop2, const float* gamma, const float* beta, float eps, void* Z, void* X,
+              float* mean, float* rstd, void* gate_bits, int frames, int S, int D, int F, iq_stream_t stream) {
   if (frames <= 0) return IQ_OK;
   if (!X1 || !W1 || !b1 || !H || !W2 || !b2 || !gamma || !beta || !Z || !X || !mean || !rstd) return IQ_ERR_ARG;
   if (!iq_ffn_chain_supported(S, D, F)) return IQ_ERR_UNSUPPORTED;
@@ -811,11 +1083,49 @@ extern "C" int iq_ffn_chain_fwd(const void* X1, const void* W1, const float* b1,
   };
   if (!fill(drop1, &p.drop1_on, &p.rng1, &p.thresh1, &p.dscale1) || !fill(drop2, &p.drop2_on, &p.rng2, &p.thresh2, &p.dscale2))
     return IQ_ERR_ARG;
+  if (pre) {
+    if (!pre->A0 || !pre->W0 || !pre->b0 || !pre->R0 || !pre->gamma0 || !pre->beta0 || !pre->Z0 || !pre->mean0 || !pre->rstd0)
+      return IQ_ERR_ARG;
+    if (((uintptr_t)pre->A0 | (uintptr_t)pre->W0 | (uintptr_t)pre->b0 | (uintptr_t)pre->R0 | (uintptr_t)pre->gamma0 |
+         (uintptr_t)pre->beta0 | (uintptr_t)pre->Z0) % 16) return IQ_ERR_ARG;
+    p.A0 = (const bf16*)pre->A0; p.W0 = (const bf16*)pre->W0; p.R0 = (const bf16*)pre->R0; p.b0 = pre->b0;
+    p.gamma0 = pre->gamma0; p.beta0 = pre->beta0; p.Z0 = (bf16*)pre->Z0; p.X1out = (bf16*)X1; p.mean0 = pre->mean0; p.rstd0 = pre->rstd0;
+    if (!fill(pre->drop0, &p.drop0_on, &p.rng0, &p.thresh0, &p.dscale0)) return IQ_ERR_ARG;
+    if (pre->Wq || pre->bq || pre->Yq) {
+      if (!pre->Wq || !pre->bq || !pre->Yq || ((uintptr_t)pre->Wq | (uintptr_t)pre->bq | (uintptr_t)pre->Yq) % 16) return IQ_ERR_ARG;
+      p.Wq = (const bf16*)pre->Wq; p.bq = pre->bq; p.Yq = (bf16*)pre->Yq;
+    }
+  }
   hipStream_t st = (hipStream_t)stream;
   IQ_PROF(IQ_FAM_GEMM_NT, st);
   const double M = (double)p.M;
-  IQ_PROF_K(2.0 * (M * D * 3 + M * F + 2.0 * D * F) + 8.0 * M, 4.0 * M * D * F, "ffn_chain_fwd_kernel<%d, %d, %s>", D, chain_waves(p.M), p.drop1_on ? "true" : "false");
+  double more_bytes = 0.0, more_flops = 0.0;
+  if (pre) { more_bytes += 2.0 * (M * D * 3 + (double)D * D) + 8.0 * M; more_flops += 2.0 * M * D * D; }
+  if (p.Wq) { more_bytes += 2.0 * (M * 3 * D + 3.0 * D * D); more_flops += 6.0 * M * D * D; }
+  IQ_PROF_K(2.0 * (M * D * 3 + M * F + 2.0 * D * F) + 8.0 * M + more_bytes, 4.0 * M * D * F + more_flops,
+            "ffn_chain_fwd_kernel<%d, %d, %s, %d>", D, chain_waves(p.M), p.drop1_on ? "true" : "false", p.Wq ? 2 : pre ? 1 : 0);
   return D == 192 ? launch_chain_d<192>(p, st) : launch_chain_d<128>(p, st);
+}
+}  // namespace
+
+extern "C" int iq_ffn_chain_fwd(const void* X1, const void* W1, const float* b1, const iq_dropout_t* drop1, void* H,
+                                const void* W2, const float* b2, const iq_dropout_t* drop2, const float* gamma,
+                                const float* beta, float eps, void* Z, void* X, float* mean, float* rstd, void* gate_bits,
+                                int frames, int S, int D, int F, iq_stream_t stream) {
+  return chain_fwd(nullptr, X1, W1, b1, drop1, H, W2, b2, drop2, gamma, beta, eps, Z, X, mean, rstd, gate_bits, frames, S, D, F, stream);
+}
+
+// The encoder layer from the attention output on, one launch: X1 = norm1(dropout0(A Wo^T + bo) + R) (written, with Z1 / mean1 /
+// rstd1, for the backward pass), then iq_ffn_chain_fwd on it; with Wq: Yq[M,3D] = X Wq^T + bq behind it (the next layer's q,k,v).
+// Same eps for both norms.
+extern "C" int iq_attn_out_ffn_chain_fwd(const void* A, const void* Wo, const float* bo, const iq_dropout_t* drop0, const void* R,
+                                         const float* gamma1, const float* beta1, void* Z1, void* X1, float* mean1, float* rstd1,
+                                         const void* W1, const float* b1, const iq_dropout_t* drop1, void* H, const void* W2,
+                                         const float* b2, const iq_dropout_t* drop2, const float* gamma2, const float* beta2, float eps,
+                                         void* Z2, void* X, float* mean2, float* rstd2, void* gate_bits, const void* Wq,
+                                         const float* bq, void* Yq, int frames, int S, int D, int F, iq_stream_t stream) {
+  const ChainPre pre = {A, Wo, bo, drop0, R, gamma1, beta1, Z1, mean1, rstd1, Wq, bq, Yq};
+  return chain_fwd(&pre, X1, W1, b1, drop1, H, W2, b2, drop2, gamma2, beta2, eps, Z2, X, mean2, rstd2, gate_bits, frames, S, D, F, stream);
 }
 
 extern "C" int iq_ffn_chain_bwd_partial_rows(int M) {      // one per workgroup

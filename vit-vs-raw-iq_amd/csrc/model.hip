@@ -256,6 +256,13 @@ inline bool use_ffn_chain(int M, int S, int D, int F) {
   return M > 32768;
 }
 
+// ... with the attention output projection + norm1 as its first stage (IQ_TUNE_CHAIN_PRE=0: the projection stays a launch of its own)
+// and the next layer's q,k,v projection as its last (2, default; 1: without)
+inline int use_chain_pre() {
+  static const int tune = [] { const char* e = getenv("IQ_TUNE_CHAIN_PRE"); return e ? atoi(e) : 2; }();
+  return tune;
+}
+
 #define IQ_TRY(expr, what)                                                              \
   do {                                                                                  \
     int rc_ = (expr);                                                                   \
@@ -484,17 +491,38 @@ extern "C" int iq_model_forward(iq_model_t* m, const float* src, int batch, void
            "embedding GEMM");
   }
   const unsigned char* x = ws + w.x0;
+  bool qkv_done = false;
   for (int l = 0; l < c.n_layers; ++l) {
     const LayerOff& o = m->L[l];
     const WsPlan::L& a = w.layers[l];
     iq_epilogue_t e;
     // q,k,v projections as one [3D x D] GEMM over the packed weight view
-    memset(&e, 0, sizeof(e));
-    e.bias = P + o.bqkv;
-    IQ_TRY(iq_gemm_bf16_nt(x, D, m->sh(o.wqkv), D, ws + a.qkv, 3 * D, M, 3 * D, D, &e, stream), "qkv GEMM");
+    // (not when the previous layer's last launch has already written it: iq_attn_out_ffn_chain_fwd's q,k,v stage)
+    if (!qkv_done) {
+      memset(&e, 0, sizeof(e));
+      e.bias = P + o.bqkv;
+      IQ_TRY(iq_gemm_bf16_nt(x, D, m->sh(o.wqkv), D, ws + a.qkv, 3 * D, M, 3 * D, D, &e, stream), "qkv GEMM");
+    }
+    qkv_done = false;
     IQ_TRY(iq_attn_fwd(ws + a.qkv, ws + a.att, (float*)(ws + a.lse), B, S, H, m->dh, stream), "attention fwd");
-    // out-proj + dropout1 + residual + norm1: one launch when a workgroup can own whole rows (D <= 256), else two
+    // out-proj + dropout1 + residual + norm1: one launch when a workgroup can own whole rows (D <= 256), else two -- or, where
+    // the FFN chain kernel runs, its first stage (iq_attn_out_ffn_chain_fwd: the layer from the attention output on is one launch)
     const iq_dropout_t dr1 = site(m, seed, step_dev, 1 + 3 * l, tr);
+    const iq_dropout_t drh = site(m, seed, step_dev, 2 + 3 * l, tr);
+    const iq_dropout_t dr2 = site(m, seed, step_dev, 3 + 3 * l, tr);
+    if (use_ffn_chain(M, S, D, F) && use_chain_pre()) {
+      const bool next = l + 1 < c.n_layers && use_chain_pre() >= 2;
+      IQ_TRY(iq_attn_out_ffn_chain_fwd(ws + a.att, m->sh(o.wo), P + o.bo, &dr1, x, P + o.g1, P + o.be1, ws + a.z1, ws + a.x1,
+                                       (float*)(ws + a.mean1), (float*)(ws + a.rstd1), m->sh(o.w1), P + o.b1, &drh, ws + a.hid,
+                                       m->sh(o.w2), P + o.b2, &dr2, P + o.g2, P + o.be2, 1e-12f, ws + a.z2, ws + a.x2,
+                                       (float*)(ws + a.mean2), (float*)(ws + a.rstd2), ws + a.gate,
+                                       next ? m->sh(m->L[l + 1].wqkv) : nullptr, next ? P + m->L[l + 1].bqkv : nullptr,
+                                       next ? ws + w.layers[l + 1].qkv : nullptr, B, S, D, F, stream),
+             "out-proj + norm1 + ffn chain + norm2 (+ next q,k,v)");
+      qkv_done = next;
+      x = ws + a.x2;
+      continue;
+    }
     if (use_fused_ln(D, D)) {
       IQ_TRY(iq_gemm_bf16_ln(ws + a.att, D, m->sh(o.wo), D, P + o.bo, x, D, &dr1, P + o.g1, P + o.be1, 1e-12f, ws + a.z1,
                              ws + a.x1, (float*)(ws + a.mean1), (float*)(ws + a.rstd1), M, D, D, stream), "out-proj GEMM + norm1");
@@ -506,8 +534,6 @@ extern "C" int iq_model_forward(iq_model_t* m, const float* src, int batch, void
     }
     // ffn + dropout2 + residual + norm2: one launch per layer where a frame's rows fit one workgroup (iq_ffn_chain_fwd: the
     // hidden activation is consumed from LDS), else FFN1 then FFN2 (+ norm2 in its epilogue where a workgroup owns whole rows)
-    const iq_dropout_t drh = site(m, seed, step_dev, 2 + 3 * l, tr);
-    const iq_dropout_t dr2 = site(m, seed, step_dev, 3 + 3 * l, tr);
     if (use_ffn_chain(M, S, D, F)) {
       IQ_TRY(iq_ffn_chain_fwd(ws + a.x1, m->sh(o.w1), P + o.b1, &drh, ws + a.hid, m->sh(o.w2), P + o.b2, &dr2, P + o.g2, P + o.be2,
                               1e-12f, ws + a.z2, ws + a.x2, (float*)(ws + a.mean2), (float*)(ws + a.rstd2), ws + a.gate, B, S, D, F, stream),
