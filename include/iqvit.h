@@ -136,14 +136,17 @@ int iq_gemm_bf16_lnbwd(const void* A, int lda, const void* Wt, int ldw, const vo
  *   dX1 = gH * W1t^T + residual (rounded to bf16), then exactly iq_ln_bwd on it with z1 / mean / rstd / gamma:
  *   dz bf16 [M,D], dy = dropout_mask(dz) * scale (only when drop->p > 0), partial: iq_ffn_chain_bwd_partial_rows(M) rows of
  *   [2*D] fp32 (dgamma | dbeta partial sums, one row per workgroup) for the fused fixed-order reduction (iq_reduce_seg_t).
- * W2t [F, D] and W1t [D, F] are the TRANSPOSED weights (bf16 row-major), M = frames * S. */
+ * W2t [F, D] and W1t [D, F] are the TRANSPOSED weights (bf16 row-major), M = frames * S.
+ * Wot / dA (both or neither): dA[M, D] = dy * Wot[D, D]^T behind it (dz where there is no dropout) -- the data gradient of the
+ * attention output projection (Wot = Wo transposed; autograd of multi_head_attention.py:28), i.e. what iq_attn_bwd starts
+ * from, in the same launch: equals iq_gemm_bf16_nt(dy, Wot) up to bf16 rounding ties. */
 int iq_ffn_chain_supported(int S, int D, int F);
 int iq_ffn_chain_bwd_partial_rows(int M);
 size_t iq_ffn_chain_gate_bytes(int M, int F);
 int iq_ffn_chain_bwd(const void* dO, const void* W2t, const void* gate_bits, float gate_scale, void* gH, const void* W1t,
                      const void* residual, const void* z1, const float* mean, const float* rstd, const float* gamma,
-                     const iq_dropout_t* drop, void* dz, void* dy, float* partial, int frames, int S, int D, int F,
-                     iq_stream_t stream);
+                     const iq_dropout_t* drop, void* dz, void* dy, float* partial, const void* Wot, void* dA, int frames, int S,
+                     int D, int F, iq_stream_t stream);
 int iq_ffn_chain_fwd(const void* X1, const void* W1, const float* b1, const iq_dropout_t* drop1, void* H, const void* W2,
                      const float* b2, const iq_dropout_t* drop2, const float* gamma, const float* beta, float eps, void* Z,
                      void* X, float* mean, float* rstd, void* gate_bits, int frames, int S, int D, int F, iq_stream_t stream);

@@ -37,7 +37,13 @@ gH1 = torch.zeros(M, F, device=d, dtype=torch.bfloat16); dz1 = torch.zeros_like(
 rows1 = L.iq_ffn_chain_bwd_partial_rows(M); part1 = torch.zeros(rows1, 2 * D, device=d)
 def one():
     N.check(L.iq_ffn_chain_bwd(dO.data_ptr(), W2t.data_ptr(), gate.data_ptr(), scale, gH1.data_ptr(), W1t.data_ptr(), R.data_ptr(), z.data_ptr(), mean.data_ptr(),
-                               rstd.data_ptr(), gm.data_ptr(), dr, dz1.data_ptr(), dy1.data_ptr(), part1.data_ptr(), frames, S, D, F, st()), "chain_bwd")
+                               rstd.data_ptr(), gm.data_ptr(), dr, dz1.data_ptr(), dy1.data_ptr(), part1.data_ptr(), None, None, frames, S, D, F, st()), "chain_bwd")
+Wot = (torch.randn(D, D, device=d) / D ** 0.5).bfloat16(); dA = torch.zeros_like(z); dA0 = torch.zeros_like(z)
+def one_dA():
+    N.check(L.iq_ffn_chain_bwd(dO.data_ptr(), W2t.data_ptr(), gate.data_ptr(), scale, gH1.data_ptr(), W1t.data_ptr(), R.data_ptr(), z.data_ptr(), mean.data_ptr(),
+                               rstd.data_ptr(), gm.data_ptr(), dr, dz1.data_ptr(), dy1.data_ptr(), part1.data_ptr(), Wot.data_ptr(), dA.data_ptr(), frames, S, D, F, st()), "chain_bwd")
+def outproj():
+    N.check(L.iq_gemm_bf16_nt((dy1 if dr is not None else dz1).data_ptr(), D, Wot.data_ptr(), D, dA0.data_ptr(), D, M, D, D, None, st()), "out-proj dgrad")
 two(); one(); torch.cuda.synchronize()
 for name, a, b in (("gH", gH0, gH1), ("dZ", dz0, dz1), ("dY", dy0, dy1)):
     ne = a.view(torch.int16) != b.view(torch.int16)
@@ -52,4 +58,4 @@ def timeit(fn, reps=20):
     for _ in range(reps): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps * 1e3
-print(f"two launches {timeit(two):.1f} us, chain {timeit(one):.1f} us")
+print(f"two launches {timeit(two):.1f} us, chain {timeit(one):.1f} us; out-proj dgrad {timeit(outproj):.1f} us, chain with it {timeit(one_dA):.1f} us")

@@ -472,12 +472,14 @@ def test_attn_out_ffn_chain_equals_gemm_ln_then_ffn_chain(L, frames, S, D, F, pd
 @pytest.mark.parametrize("frames,S,D,F,pdrop", [(256, 197, 192, 768, 0.1), (7, 197, 192, 832, 0.0), (256, 65, 128, 1024, 0.2),
                                                  (5, 5, 128, 512, 0.0), (3, 224, 192, 128, 0.3), (9, 17, 128, 896, 0.1),
                                                  (40, 197, 192, 64, 0.1), (2, 1, 192, 256, 0.0)])
-def test_ffn_chain_backward_equals_gate_gemm_then_dgrad_layernorm_backward(L, frames, S, D, F, pdrop):
+@pytest.mark.parametrize("with_dA", [False, True])
+def test_ffn_chain_backward_equals_gate_gemm_then_dgrad_layernorm_backward(L, frames, S, D, F, pdrop, with_dA):
     """iq_ffn_chain_bwd (gate data gradient + FFN1 data gradient + residual + norm1 backward in one launch, gate = the "H > 0"
     bits iq_ffn_chain_fwd leaves) against the two launches it replaces -- iq_gemm_bf16_nt with the gate epilogue on H itself,
     then iq_gemm_bf16_lnbwd: gH / dZ / dY equal except at rounding ties (k-values enter the MFMAs in another lane-group
     order), identical dropout masks, gamma / beta partial sums to fp32 summation order; F / 64 = 12, 13, 14 chunks exercise the
-    three phases of the ring in which the tail borrows its scratch."""
+    three phases of the ring in which the tail borrows its scratch.  with_dA: the attention output projection's data gradient
+    (autograd of multi_head_attention.py:28) in the same launch against iq_gemm_bf16_nt on the dY written."""
     N = _N()
     M = frames * S
     g = torch.Generator(device="cuda").manual_seed(M + D + F)
@@ -515,9 +517,19 @@ def test_ffn_chain_backward_equals_gate_gemm_then_dgrad_layernorm_backward(L, fr
     units = (M + 31) // 32
     assert rows in ((units + 1) // 2, (units + 3) // 4, (units + 6) // 7)          # one row per workgroup of 2 | 4 | 7 waves
     part1 = torch.full((rows, 2 * D), nan, device=dev())
+    Wot = bf(torch.randn(D, D, device=dev(), generator=g) / math.sqrt(D))
+    dA = torch.full((M, D), nan, dtype=torch.bfloat16, device=dev())
     N.check(L.iq_ffn_chain_bwd(dO.data_ptr(), W2t.data_ptr(), gate.data_ptr(), scale, gH1.data_ptr(), W1t.data_ptr(), R.data_ptr(), z.data_ptr(),
                                mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), C.byref(dr) if pdrop > 0 else None, dz1.data_ptr(),
-                               dy1.data_ptr(), part1.data_ptr(), frames, S, D, F, stream()), "ffn_chain_bwd")
+                               dy1.data_ptr(), part1.data_ptr(), Wot.data_ptr() if with_dA else None, dA.data_ptr() if with_dA else None,
+                               frames, S, D, F, stream()), "ffn_chain_bwd")
+    if with_dA:        # the output projection's data gradient of the dY (dZ without dropout) this launch wrote
+        dAr = run_gemm(L, dy1 if pdrop > 0 else dz1, Wot, M, D, D)
+        assert torch.isfinite(dA.float()).all()
+        ne = dA.view(torch.int16) != dAr.view(torch.int16)
+        assert ne.float().mean().item() <= 3e-3, ne.float().mean().item()
+        excess = (dA.float() - dAr.float()).abs() - (torch.maximum(dA.float().abs(), dAr.float().abs()) * 2 ** -7 + 1e-5 * dAr.float().abs().max().item())
+        assert excess.max().item() <= 0.0, excess.max().item()
     def ties_only(a, b, what, frac, abs_):
         ne = a.view(torch.int16) != b.view(torch.int16)
         assert ne.float().mean().item() <= frac, f"{what}: {ne.float().mean().item():.3g} of the elements differ"

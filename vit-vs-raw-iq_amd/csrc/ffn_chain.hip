@@ -645,9 +645,14 @@ struct FfnChainBwdParams {
   int M, F;
   float gate_scale;
   int drop_on; IqRng rng; uint32_t thresh; float dscale;
+  // optional last stage (POSTB): dA[M,D] = dY * Wot[D,D]^T -- the attention output projection's data gradient (Wot = Wo transposed)
+  const bf16* Wot; bf16* dA;
 };
 
-template <int D, int NW, bool DROP>
+// POSTB: the tail's dY rows go back into the wave's LDS image, are re-read as MFMA activation fragments and multiplied with the
+// transposed projection weight (64-row blocks in the ring slots the loop has left): dA = dY Wo, the gradient the attention
+// backward starts from, without dY's round trip through HBM and one launch less.
+template <int D, int NW, bool DROP, bool POSTB>
 __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChainBwdParams p) {
   constexpr int XCPR = D / 8;
   constexpr int KS1 = D / 32;
@@ -849,12 +854,28 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
   constexpr int IMG = 32 * LDI * 2;                     // bytes per wave: 12,288 | 8,192
   static_assert(SLOT % IMG == 0 && FC_MAXW <= 2 * (SLOT / IMG), "whole wave images, seven of them in the two dead ring slots");
   bf16* img;
+  const int sC = (nchunk - 1) % FC_NS;                  // the last chunk's slot (slower waves may still be reading it)
+  const int s2 = (sC + 2) % FC_NS, s3 = (sC + 1) % FC_NS;
   {
-    const int s2 = (nchunk >= 2 ? nchunk - 2 : 1) % FC_NS, s3 = (nchunk >= 2 ? nchunk : 2) % FC_NS;     // (nchunk - 3) % 3 == nchunk % 3
     const int per = SLOT / IMG;                         // whole images per slot
     img = reinterpret_cast<bf16*>(smem + (wave < per ? s2 * SLOT + wave * IMG : s3 * SLOT + (wave - per) * IMG));
   }
-  float* wsum = reinterpret_cast<float*>(img);          // [2 D]: this wave's column sums, parked over its (then dead) image
+  float* wsum = reinterpret_cast<float*>(smem + FC_NS * SLOT) + wave * (2 * D);      // [2 D]: this wave's column sums, behind the ring
+  constexpr int NB0 = D / FC_CHUNK;                     // 64-row blocks of the transposed projection weight: 3 | 2
+  auto issue_wot = [&](int b0, int nb, unsigned char* dst) {       // blocks b0 .. b0 + nb - 1 as W1-type images at dst
+    const int pieces = nb * W1_PIECES;
+    for (int pc = wave; pc < pieces; pc += NW) {
+      const int lin = pc * 64 + lane;
+      const int r = lin / XCPR, sl = lin - r * XCPR;
+      const int q = fc_swz<XCPR>(r & 63, sl);
+      const unsigned off = (unsigned)(((b0 * FC_CHUNK + r) * D + ((q & ~3) | fc_kperm(q & 3)) * 8) * 2);
+      __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(reinterpret_cast<const char*>(p.Wot) + off), (lds_void_t*)(dst + pc * 1024), 16, 0, 0);
+    }
+  };
+  if (POSTB) {
+    __syncthreads();                                    // every wave has left the loop: the last chunk's slot is free
+    issue_wot(0, 2, smem + sC * SLOT);                  // (in flight under the LayerNorm backward below)
+  }
   if (have) {
 #pragma unroll
   for (int rg = 0; rg < 2; ++rg) {
@@ -926,18 +947,28 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = rstd * (dy[v][e] - c1 - xh[v][e] * c2);
           const long off = row * D + (v * LPR + lj) * 8;
-          *reinterpret_cast<bf16x8*>(p.dZ + off) = pack8(o);
+          bf16x8 ob = pack8(o);
+          *reinterpret_cast<bf16x8*>(p.dZ + off) = ob;
           if (DROP) {
             const uint32_t keep = dropout_keep8(rng, (uint64_t)off >> 3, p.thresh);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = ((keep >> e) & 1u) ? o[e] * p.dscale : 0.f;
-            *reinterpret_cast<bf16x8*>(p.dY + off) = pack8(o);
+            ob = pack8(o);
+            *reinterpret_cast<bf16x8*>(p.dY + off) = ob;
           }
+          if (POSTB) *reinterpret_cast<bf16x8*>(img + rl * LDI + (v * LPR + lj) * 8) = ob;      // (where this lane read dX1 from)
         }
       }
     }
+    if (POSTB) {                                        // dY rows as activation fragments (the dO fragments are dead)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks)
+          xf[rg][ks] = *reinterpret_cast<const bf16x8*>(img + (rg * 16 + c16) * LDI + 32 * ks + 8 * fc_kperm(g));
+    }
     // column sums over the wave's 32 rows: lanes with the same lj hold the same columns (8 row slots): fixed-order shuffles
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the image has been read: the sums may overwrite its head)
     float* prow = wsum;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -962,16 +993,62 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
   }
   // one partial row per WORKGROUP: the waves' sums added in wave order (fixed: reproducible) -- seven times fewer rows for the
   // layer's slab reduce than one per wave
+  if (POSTB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of weight blocks 0 and 1 (and its stores)
   __syncthreads();
-  {
-    constexpr int per = SLOT / IMG;
-    const int s2 = (nchunk >= 2 ? nchunk - 2 : 1) % FC_NS, s3 = (nchunk >= 2 ? nchunk : 2) % FC_NS;
-    for (int i = tid; i < 2 * D; i += NW * 64) {
-      float t = 0.f;
+  if (POSTB && NB0 > 2) issue_wot(2, NB0 - 2, smem + s2 * SLOT);    // (the images are dead now)
+  for (int i = tid; i < 2 * D; i += NW * 64) {
+    float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w)
-        t += reinterpret_cast<const float*>(smem + (w < per ? s2 * SLOT + w * IMG : s3 * SLOT + (w - per) * IMG))[i];
-      p.partial[(long)blockIdx.x * (2 * D) + i] = t;
+    for (int w = 0; w < NW; ++w) t += reinterpret_cast<const float*>(smem + FC_NS * SLOT)[w * (2 * D) + i];
+    p.partial[(long)blockIdx.x * (2 * D) + i] = t;
+  }
+  if (!POSTB) return;
+  // ---- POSTB: dA = dY Wot^T, 64 output columns (one weight block) at a time ----------------------------------------------------
+#pragma unroll
+  for (int b = 0; b < NB0; ++b) {
+    if (b == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    if (!have) continue;
+    const uint32_t blk = lds0 + (b < 2 ? sC * SLOT + b * W1_BYTES : s2 * SLOT);
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      f32x4 acc1[2][2];
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg) { acc1[rg][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      bf16x8 wp[2][2];
+      auto read_w = [&](int ks, bf16x8 (&dst)[2]) {
+        const uint32_t a0 = blk + w1at(ks);
+        if (jp == 0) { lds_read128<0 * 16 * D * 2>(dst[0], a0); lds_read128<1 * 16 * D * 2>(dst[1], a0); }
+        else { lds_read128<2 * 16 * D * 2>(dst[0], a0); lds_read128<3 * 16 * D * 2>(dst[1], a0); }
+      };
+      read_w(0, wp[0]);
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) {
+        if (ks + 1 < KS1) { read_w(ks + 1, wp[(ks + 1) & 1]); FC_LGKM_WAIT(2); }
+        else FC_LGKM_WAIT(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc1[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[0][ks], acc1[0][t], 0, 0, 0);
+          acc1[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[1][ks], acc1[1][t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int col = FC_CHUNK * b + 32 * jp + (odd ? 16 + 4 * (g - 1) : 4 * g);
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg) {
+        float w[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float va = acc1[rg][0][r], vb = acc1[rg][1][r];
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
+          w[r] = __uint_as_float(sw[0]);
+          w[4 + r] = __uint_as_float(sw[1]);
+        }
+        const long grow = row0 + rg * 16 + c16;
+        if (grow < p.M) *reinterpret_cast<bf16x8*>(p.dA + grow * D + col) = pack8(w);
+      }
     }
   }
 }
@@ -1015,18 +1092,18 @@ int launch_chain_d(const FfnChainParams& p, hipStream_t st) {
 template <int D, int NW>
 int launch_chain_bwd(const FfnChainBwdParams& p, hipStream_t st) {
   constexpr int SLOT = 2 * FC_CHUNK * D * 2;
-  const size_t lds = (size_t)FC_NS * SLOT;
+  const size_t lds = (size_t)FC_NS * SLOT + (size_t)NW * 2 * D * sizeof(float);     // ring + the waves' gamma / beta column sums
   const long units = ((long)p.M + 31) / 32;
   const int grid = (int)((units + NW - 1) / NW);
-#define FC_LAUNCHB(DROP_)                                                                                                     \
+#define FC_LAUNCHB(DROP_, POST_)                                                                                              \
   do {                                                                                                                        \
-    auto k = ffn_chain_bwd_kernel<D, NW, DROP_>;                                                                              \
+    auto k = ffn_chain_bwd_kernel<D, NW, DROP_, POST_>;                                                                       \
     static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     (void)attr;                                                                                                               \
     k<<<grid, NW * 64, lds, st>>>(p);                                                                                         \
   } while (0)
-  if (p.drop_on) FC_LAUNCHB(true);
-  else FC_LAUNCHB(false);
+  if (p.Wot) { if (p.drop_on) FC_LAUNCHB(true, true); else FC_LAUNCHB(false, true); }
+  else { if (p.drop_on) FC_LAUNCHB(true, false); else FC_LAUNCHB(false, false); }
 #undef FC_LAUNCHB
   return iq_launch_status();
 }
@@ -1141,9 +1218,10 @@ extern "C" size_t iq_ffn_chain_gate_bytes(int M, int F) {
 
 extern "C" int iq_ffn_chain_bwd(const void* dO, const void* W2t, const void* gate_bits, float gate_scale, void* gH, const void* W1t,
                                 const void* residual, const void* z1, const float* mean, const float* rstd, const float* gamma,
-                                const iq_dropout_t* drop, void* dz, void* dy, float* partial, int frames, int S, int D, int F,
-                                iq_stream_t stream) {
+                                const iq_dropout_t* drop, void* dz, void* dy, float* partial, const void* Wot, void* dA, int frames,
+                                int S, int D, int F, iq_stream_t stream) {
   if (frames <= 0) return IQ_OK;
+  if ((Wot == nullptr) != (dA == nullptr) || ((uintptr_t)Wot | (uintptr_t)dA) % 16) return IQ_ERR_ARG;
   if (!dO || !W2t || !gate_bits || !gH || !W1t || !residual || !z1 || !mean || !rstd || !gamma || !dz || !partial) return IQ_ERR_ARG;
   if (!iq_ffn_chain_supported(S, D, F)) return IQ_ERR_UNSUPPORTED;
   if (((uintptr_t)dO | (uintptr_t)W2t | (uintptr_t)W1t | (uintptr_t)gate_bits | (uintptr_t)gH | (uintptr_t)residual | (uintptr_t)z1 |
@@ -1155,6 +1233,7 @@ extern "C" int iq_ffn_chain_bwd(const void* dO, const void* W2t, const void* gat
   p.mean = mean; p.rstd = rstd; p.gamma = gamma;
   p.gH = (bf16*)gH; p.dZ = (bf16*)dz; p.dY = (bf16*)dy; p.partial = partial;
   p.M = frames * S; p.F = F; p.gate_scale = gate_scale;
+  p.Wot = (const bf16*)Wot; p.dA = (bf16*)dA;
   if (drop && drop->p > 0.f) {
     if (drop->p >= 1.f || !dy) return IQ_ERR_ARG;
     p.drop_on = 1;
@@ -1165,7 +1244,8 @@ extern "C" int iq_ffn_chain_bwd(const void* dO, const void* W2t, const void* gat
   hipStream_t st = (hipStream_t)stream;
   IQ_PROF(IQ_FAM_GEMM_NT, st);
   const double M = (double)p.M;
-  IQ_PROF_K(2.0 * (M * D * (4 + (p.drop_on ? 1 : 0)) + 2.0 * M * F + 2.0 * D * F) + 8.0 * M, 4.0 * M * D * F, "ffn_chain_bwd_kernel<%d, %d, %s>", D,
-            chain_waves(p.M), p.drop_on ? "true" : "false");
+  IQ_PROF_K(2.0 * (M * D * (4 + (p.drop_on ? 1 : 0) + (Wot ? 1 : 0)) + 2.0 * M * F + 2.0 * D * F + (Wot ? (double)D * D : 0.0)) + 8.0 * M,
+            4.0 * M * D * F + (Wot ? 2.0 * M * D * D : 0.0), "ffn_chain_bwd_kernel<%d, %d, %s, %s>", D, chain_waves(p.M),
+            p.drop_on ? "true" : "false", Wot ? "true" : "false");
   return D == 192 ? launch_chain_bwd_d<192>(p, st) : launch_chain_bwd_d<128>(p, st);
 }

@@ -649,9 +649,11 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
     const iq_reduce_seg_t lnseg[4] = {{lp2, rows2, 2L * D, G + o.g2, D}, {lp2 + D, rows2, 2L * D, G + o.be2, D},
                                       {lp1, rows1, 2L * D, G + o.g1, D}, {lp1 + D, rows1, 2L * D, G + o.be1, D}};
     const iq_dropout_t dr1 = m->bwd_site(1 + 3 * l, step_dev, tr);
+    const bool post = chain && use_chain_pre() >= 2;       // ... and the output projection's data gradient behind it
     if (chain) {
       IQ_TRY(iq_ffn_chain_bwd(dO2, m->sht(o.t_w2), ws + a.gate, dscale, gH, m->sht(o.t_w1), gZ, ws + a.z1, (const float*)(ws + a.mean1),
-                              (const float*)(ws + a.rstd1), P + o.g1, &dr1, gZ1, gY1, lp1, B, S, D, F, stream), "ffn chain bwd + norm1 bwd");
+                              (const float*)(ws + a.rstd1), P + o.g1, &dr1, gZ1, gY1, lp1, post ? m->sht(o.t_wo) : nullptr,
+                              post ? ws + w.gAtt : nullptr, B, S, D, F, stream), "ffn chain bwd + norm1 bwd (+ out-proj dgrad)");
     } else {
       memset(&e, 0, sizeof(e));
       e.gate = ws + a.hid; e.ldg = F; e.gate_scale = dscale;
@@ -668,7 +670,7 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
                          gZ1, gY1, &dr1, nullptr, nullptr, lp1, accumulate, M, D, stream), "norm1 bwd");
       }
     }
-    IQ_TRY(iq_gemm_bf16_nt(dAo, D, m->sht(o.t_wo), D, ws + w.gAtt, D, M, D, D, nullptr, stream), "out-proj dgrad");
+    if (!post) IQ_TRY(iq_gemm_bf16_nt(dAo, D, m->sht(o.t_wo), D, ws + w.gAtt, D, M, D, D, nullptr, stream), "out-proj dgrad");
     IQ_TRY(iq_attn_bwd(ws + a.qkv, ws + a.att, ws + w.gAtt, (const float*)(ws + a.lse), gQKV, B, S, H, m->dh, stream), "attention bwd");
     // The four weight gradients of the layer, BEFORE the QKV data gradient: fused with the norm2 backward of the layer
     // below, that GEMM overwrites gZ / gY and the norm2 partial rows, which the weight gradients / their reduce still read.
