@@ -139,7 +139,13 @@ int iq_gemm_bf16_lnbwd(const void* A, int lda, const void* Wt, int ldw, const vo
  * W2t [F, D] and W1t [D, F] are the TRANSPOSED weights (bf16 row-major), M = frames * S.
  * Wot / dA (both or neither): dA[M, D] = dy * Wot[D, D]^T behind it (dz where there is no dropout) -- the data gradient of the
  * attention output projection (Wot = Wo transposed; autograd of multi_head_attention.py:28), i.e. what iq_attn_bwd starts
- * from, in the same launch: equals iq_gemm_bf16_nt(dy, Wot) up to bf16 rounding ties. */
+ * from, in the same launch: equals iq_gemm_bf16_nt(dy, Wot) up to bf16 rounding ties.
+ * iq_qkv_dgrad_ffn_chain_bwd: the same launch (Wot / dA required) with the launch that would produce its dO in front -- exactly
+ * iq_gemm_bf16_lnbwd(gQKV [M,3D], Wqkv_t [D,3D], residual0, z2, mean2, rstd2, gamma2, drop2) -> dz2, dy2, partial2
+ * (iq_ffn_chain_bwd_partial_rows(M) rows): the data gradient of the packed q,k,v projection of the layer ABOVE
+ * (multi_head_attention.py:17-19) + the residual path, and this layer's norm2 backward (encoder_layer.py:30-33).  dy2 (dz2 where
+ * there is no dropout; same probability at both sites) is the second stage's dO, taken from the CU's LDS instead of HBM;
+ * `residual` is normally dz2 itself.  Results equal the two launches up to bf16 rounding ties. */
 int iq_ffn_chain_supported(int S, int D, int F);
 int iq_ffn_chain_bwd_partial_rows(int M);
 size_t iq_ffn_chain_gate_bytes(int M, int F);
@@ -147,6 +153,11 @@ int iq_ffn_chain_bwd(const void* dO, const void* W2t, const void* gate_bits, flo
                      const void* residual, const void* z1, const float* mean, const float* rstd, const float* gamma,
                      const iq_dropout_t* drop, void* dz, void* dy, float* partial, const void* Wot, void* dA, int frames, int S,
                      int D, int F, iq_stream_t stream);
+int iq_qkv_dgrad_ffn_chain_bwd(const void* gQKV, const void* Wqkv_t, const void* residual0, const void* z2, const float* mean2,
+                               const float* rstd2, const float* gamma2, const iq_dropout_t* drop2, void* dz2, void* dy2, float* partial2,
+                               const void* W2t, const void* gate_bits, float gate_scale, void* gH, const void* W1t, const void* residual,
+                               const void* z1, const float* mean, const float* rstd, const float* gamma, const iq_dropout_t* drop, void* dz,
+                               void* dy, float* partial, const void* Wot, void* dA, int frames, int S, int D, int F, iq_stream_t stream);
 int iq_ffn_chain_fwd(const void* X1, const void* W1, const float* b1, const iq_dropout_t* drop1, void* H, const void* W2,
                      const float* b2, const iq_dropout_t* drop2, const float* gamma, const float* beta, float eps, void* Z,
                      void* X, float* mean, float* rstd, void* gate_bits, int frames, int S, int D, int F, iq_stream_t stream);

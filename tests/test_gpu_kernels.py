@@ -515,7 +515,7 @@ def test_ffn_chain_backward_equals_gate_gemm_then_dgrad_layernorm_backward(L, fr
     gH1 = torch.full((M, F), nan, dtype=torch.bfloat16, device=dev()); dz1 = torch.full_like(z, nan); dy1 = torch.zeros_like(z)
     rows = L.iq_ffn_chain_bwd_partial_rows(M)
     units = (M + 31) // 32
-    assert rows in ((units + 1) // 2, (units + 3) // 4, (units + 6) // 7)          # one row per workgroup of 2 | 4 | 7 waves
+    assert rows == (units + 6) // 7                          # one row per workgroup of 7 waves
     part1 = torch.full((rows, 2 * D), nan, device=dev())
     Wot = bf(torch.randn(D, D, device=dev(), generator=g) / math.sqrt(D))
     dA = torch.full((M, D), nan, dtype=torch.bfloat16, device=dev())
@@ -544,6 +544,79 @@ def test_ffn_chain_backward_equals_gate_gemm_then_dgrad_layernorm_backward(L, fr
     s0, s1 = part0.sum(0), part1.sum(0)
     assert torch.isfinite(part1).all()
     close_f32(s1, s0, "dgamma | dbeta", 2e-3)
+
+
+@pytest.mark.parametrize("frames,S,D,F,pdrop", [(256, 197, 192, 768, 0.1), (7, 197, 192, 832, 0.0), (256, 65, 128, 1024, 0.2),
+                                                 (5, 5, 128, 512, 0.0), (40, 197, 192, 64, 0.1), (2, 1, 192, 128, 0.0), (9, 17, 128, 896, 0.1)])
+def test_qkv_dgrad_ffn_chain_backward_equals_its_two_launches(L, frames, S, D, F, pdrop):
+    """iq_qkv_dgrad_ffn_chain_bwd (q,k,v data gradient of the layer above + norm2 backward + the feed-forward backward + norm1
+    backward + output-projection data gradient: encoder_layer.py:24-33 backwards, one launch) against iq_gemm_bf16_lnbwd for
+    its first stage (dz2 / dy2 equal except at rounding ties, gamma / beta partial sums to fp32 summation order) and, bit for
+    bit, against iq_ffn_chain_bwd run on the dy2 / dz2 it wrote."""
+    N = _N()
+    M = frames * S
+    g = torch.Generator(device="cuda").manual_seed(M + D + F + 2)
+    rnd = lambda *shape, s=1.0: bf(torch.randn(*shape, device=dev(), generator=g) * s)
+    # forward pass of the feed-forward sub-layer: gate bits
+    X1 = rnd(M, D); W1 = rnd(F, D, s=1 / math.sqrt(D)); W2 = rnd(D, F, s=1 / math.sqrt(F))
+    b1, b2 = torch.randn(F, device=dev(), generator=g), torch.randn(D, device=dev(), generator=g)
+    gam = [torch.rand(D, device=dev(), generator=g) + 0.5 for _ in range(2)]
+    beta = torch.randn(D, device=dev(), generator=g)
+    nan = float("nan")
+    new = lambda *shape, dt=torch.bfloat16: torch.full(shape, nan, dtype=dt, device=dev())
+    H, Zf, Xf, mf, rf = new(M, F), new(M, D), new(M, D), new(M, dt=torch.float32), new(M, dt=torch.float32)
+    gate = torch.zeros(L.iq_ffn_chain_gate_bytes(M, F), dtype=torch.uint8, device=dev())
+    d1 = _drop(3, 1, 2, pdrop)
+    dp = lambda d: C.byref(d) if pdrop > 0 else None
+    N.check(L.iq_ffn_chain_fwd(X1.data_ptr(), W1.data_ptr(), b1.data_ptr(), dp(d1), H.data_ptr(), W2.data_ptr(), b2.data_ptr(), None,
+                               gam[0].data_ptr(), beta.data_ptr(), 1e-12, Zf.data_ptr(), Xf.data_ptr(), mf.data_ptr(), rf.data_ptr(),
+                               gate.data_ptr(), frames, S, D, F, stream()), "ffn_chain_fwd")
+    # backward operands
+    gQKV = rnd(M, 3 * D); Wqt = rnd(D, 3 * D, s=1 / math.sqrt(3 * D)); R0 = rnd(M, D)
+    W2t = W2.t().contiguous(); W1t = W1.t().contiguous(); Wot = rnd(D, D, s=1 / math.sqrt(D))
+    z = [rnd(M, D, s=1.5) + 0.3 for _ in range(2)]                           # z2, z1
+    z = [bf(t) for t in z]
+    mean = [t.float().mean(-1).contiguous() for t in z]
+    rstd = [(1.0 / torch.sqrt(t.float().var(-1, unbiased=False) + 1e-12)).contiguous() for t in z]
+    dr2, dr1 = _drop(77, 5, 9, pdrop), _drop(77, 5, 7, pdrop)
+    scale = 65536.0 / (65536.0 - round(pdrop * 65536)) if pdrop > 0 else 1.0
+    # reference first stage
+    dz2r, dy2r = new(M, D), torch.zeros(M, D, dtype=torch.bfloat16, device=dev())
+    p2r = torch.empty(L.iq_gemm_lnbwd_partial_rows(M), 2 * D, device=dev())
+    N.check(L.iq_gemm_bf16_lnbwd(gQKV.data_ptr(), 3 * D, Wqt.data_ptr(), 3 * D, R0.data_ptr(), D, z[0].data_ptr(), mean[0].data_ptr(),
+                                 rstd[0].data_ptr(), gam[0].data_ptr(), dp(dr2), dz2r.data_ptr(), dy2r.data_ptr(), p2r.data_ptr(), M, D,
+                                 3 * D, stream()), "gemm_lnbwd")
+    # one launch
+    rows = L.iq_ffn_chain_bwd_partial_rows(M)
+    dz2, dy2, p2 = new(M, D), torch.zeros(M, D, dtype=torch.bfloat16, device=dev()), new(rows, 2 * D, dt=torch.float32)
+    gH, dz, dy, dA, p1 = new(M, F), new(M, D), torch.zeros(M, D, dtype=torch.bfloat16, device=dev()), new(M, D), new(rows, 2 * D, dt=torch.float32)
+    N.check(L.iq_qkv_dgrad_ffn_chain_bwd(gQKV.data_ptr(), Wqt.data_ptr(), R0.data_ptr(), z[0].data_ptr(), mean[0].data_ptr(), rstd[0].data_ptr(),
+                                         gam[0].data_ptr(), dp(dr2), dz2.data_ptr(), dy2.data_ptr(), p2.data_ptr(), W2t.data_ptr(),
+                                         gate.data_ptr(), scale, gH.data_ptr(), W1t.data_ptr(), dz2.data_ptr(), z[1].data_ptr(),
+                                         mean[1].data_ptr(), rstd[1].data_ptr(), gam[1].data_ptr(), dp(dr1), dz.data_ptr(), dy.data_ptr(),
+                                         p1.data_ptr(), Wot.data_ptr(), dA.data_ptr(), frames, S, D, F, stream()), "qkv_dgrad_ffn_chain_bwd")
+    for t in (dz2, p2, gH, dz, dA, p1) + ((dy2, dy) if pdrop > 0 else ()):
+        assert torch.isfinite(t.float()).all()
+    def ties_only(a, b, what, frac, abs_):
+        ne = a.view(torch.int16) != b.view(torch.int16)
+        assert ne.float().mean().item() <= frac, f"{what}: {ne.float().mean().item():.3g} of the elements differ"
+        excess = (a.float() - b.float()).abs() - (torch.maximum(a.float().abs(), b.float().abs()) * 2 ** -7 + abs_)
+        assert excess.max().item() <= 0.0, f"{what}: more than one bf16 ulp apart ({excess.max().item():.3g})"
+    zmax = z[0].float().abs().max().item()
+    ties_only(dz2r, dz2, "dZ2", 3e-3, 4e-3 * zmax)
+    if pdrop > 0:
+        assert ((dy2r == 0) != (dy2 == 0)).float().mean().item() <= 1e-4
+        ties_only(dy2r, dy2, "dY2", 3e-3, 6e-3 * zmax)
+    close_f32(p2.sum(0), p2r.sum(0), "dgamma2 | dbeta2", 2e-3)
+    # second stage on what the fused launch wrote: identical bits
+    gHb, dzb, dyb, dAb, p1b = new(M, F), new(M, D), torch.zeros(M, D, dtype=torch.bfloat16, device=dev()), new(M, D), new(rows, 2 * D, dt=torch.float32)
+    dO = dy2 if pdrop > 0 else dz2
+    N.check(L.iq_ffn_chain_bwd(dO.data_ptr(), W2t.data_ptr(), gate.data_ptr(), scale, gHb.data_ptr(), W1t.data_ptr(), dz2.data_ptr(), z[1].data_ptr(),
+                               mean[1].data_ptr(), rstd[1].data_ptr(), gam[1].data_ptr(), dp(dr1), dzb.data_ptr(), dyb.data_ptr(), p1b.data_ptr(),
+                               Wot.data_ptr(), dAb.data_ptr(), frames, S, D, F, stream()), "ffn_chain_bwd")
+    for a_, b_, what in ((gH, gHb, "gH"), (dz, dzb, "dZ1"), (dy, dyb, "dY1"), (dA, dAb, "dA")):
+        assert torch.equal(a_.view(torch.int16), b_.view(torch.int16)), what
+    assert torch.equal(p1, p1b)
 
 
 @pytest.mark.parametrize("M,K,N_", [(5000, 768, 192), (130, 576, 192), (50432, 768, 192), (999, 384, 192), (4000, 1024, 128),

@@ -65,6 +65,8 @@ SIGNATURES = {
     "iq_ffn_chain_supported": (_I, [_I, _I, _I]),
     "iq_ffn_chain_bwd_partial_rows": (_I, [_I]),
     "iq_ffn_chain_bwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, C.POINTER(Dropout), _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "iq_qkv_dgrad_ffn_chain_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(Dropout), _P, _P, _P,
+                                        _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, C.POINTER(Dropout), _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "iq_ffn_chain_gate_bytes": (_Z, [_I, _I]),
     "iq_ffn_chain_fwd": (_I, [_P, _P, _P, C.POINTER(Dropout), _P, _P, _P, C.POINTER(Dropout), _P, _P, _F, _P, _P, _P, _P, _P, _I, _I,
                               _I, _I, _P]),

@@ -647,13 +647,23 @@ struct FfnChainBwdParams {
   int drop_on; IqRng rng; uint32_t thresh; float dscale;
   // optional last stage (POSTB): dA[M,D] = dY * Wot[D,D]^T -- the attention output projection's data gradient (Wot = Wo transposed)
   const bf16* Wot; bf16* dA;
+  // optional first stage (PREB): dO is not read but computed -- dX2 = A0[M,3D] * W0t[D,3D]^T + R0, norm2 backward on it with Z0 /
+  // mean0 / rstd0 / gamma0 (dropout site rng0, same probability): dZ0, dY0 (= dO) and partial0 are written
+  const bf16* A0; const bf16* W0t; const bf16* R0; const bf16* Z0; const float* mean0; const float* rstd0; const float* gamma0;
+  IqRng rng0; bf16* dZ0; bf16* dY0; float* partial0;
 };
 
-// POSTB: the tail's dY rows go back into the wave's LDS image, are re-read as MFMA activation fragments and multiplied with the
-// transposed projection weight (64-row blocks in the ring slots the loop has left): dA = dY Wo, the gradient the attention
-// backward starts from, without dY's round trip through HBM and one launch less.
-template <int D, int NW, bool DROP, bool POSTB>
+// MODE 1, 2 (POSTB): the tail's dY rows go back into the wave's LDS image, are re-read as MFMA activation fragments and multiplied
+// with the transposed projection weight (64-row blocks in the ring slots the loop has left): dA = dY Wo, the gradient the
+// attention backward starts from, without dY's round trip through HBM and one launch less.
+// MODE 2 (PREB): in front, the data gradient of the q,k,v projection of the layer ABOVE + this layer's norm2 backward (what
+// gemm_lnbwd.hip does as a launch of its own): dX2 = A0[M,3D] * W0t[D,3D]^T + R0 is one more "second product" -- K = 3 D walked
+// in 128-column chunk pairs through the same ring, the A0 rows fetched as fragments one pair ahead (inline-asm loads behind
+// counted waits) -- followed by the same LayerNorm-backward tail; its dY rows are this kernel's dO fragments (they never leave
+// the CU on their way into the feed-forward backward), dZ0 / dY0 / partial0 are written for the weight gradients and the tail.
+template <int D, int NW, bool DROP, int MODE>
 __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChainBwdParams p) {
+  constexpr bool POSTB = MODE >= 1, PREB = MODE == 2;
   constexpr int XCPR = D / 8;
   constexpr int KS1 = D / 32;
   constexpr int NT2 = D / 16, NP2 = NT2 / 2;
@@ -696,43 +706,9 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
       __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(base + off), (lds_void_t*)(slot + pc * 1024), 16, 0, 0);
     }
   };
-  issue_chunk(0);
-  if (nchunk > 1) issue_chunk(1);
-
-  // ---- this wave's dO rows as activation fragments; the gate rows of chunk 0 ----------------------------------------------------
   long rowc[2];
 #pragma unroll
   for (int rg = 0; rg < 2; ++rg) rowc[rg] = min(row0 + rg * 16 + c16, (long)p.M - 1);
-  bf16x8 xf[2][KS1];
-#pragma unroll
-  for (int rg = 0; rg < 2; ++rg)
-#pragma unroll
-    for (int ks = 0; ks < KS1; ++ks)
-      xf[rg][ks] = have ? *reinterpret_cast<const bf16x8*>(p.dO + rowc[rg] * D + 32 * ks + 8 * fc_kperm(g)) : bf16x8{};
-  // gate bits of chunk c for this lane's 4 x 8 hidden units: one dword, written by the forward kernel in exactly this wave /
-  // chunk / lane order.  Inline-asm load (invisible to the compiler's wait insertion: a tracked register-destination load in
-  // the loop would make it drain the ring), issued one chunk ahead, retired by the loop's own counted wait.
-  const uint32_t* gate_lane = p.gate + (row0 >> 5) * nchunk * 64 + lane;
-  uint32_t gnext;
-  auto load_gate = [&](int c) {
-    const uint32_t* src = gate_lane + c * 64;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(gnext) : "v"(src) : "memory");
-  };
-  load_gate(0);
-  const IqRng rng = DROP ? rng_resolve(p.rng) : p.rng;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int rg = 0; rg < 2; ++rg) {
-#pragma unroll
-    for (int ks = 0; ks < KS1; ++ks) asm volatile("" : "+v"(xf[rg][ks]));
-  }
-  asm volatile("" : "+v"(gnext));
-
-  f32x4 acc2[2][NT2];
-#pragma unroll
-  for (int rg = 0; rg < 2; ++rg)
-#pragma unroll
-    for (int j = 0; j < NT2; ++j) acc2[rg][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // slot-relative byte offsets of this lane's fragment reads (as in the forward kernel)
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
   // (384-byte rows: the swizzle leaves the chunk's bits above 3 alone, k-step ks reads 128 (ks >> 1) bytes behind k-step ks & 1:
@@ -744,6 +720,286 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
   for (int ks = 0; ks < KS1; ++ks) w1off[ks] = (uint32_t)(c16 * (D * 2) + fc_swz<XCPR>(c16, 4 * (ks & W1_KMASK) + g) * 16);
 #pragma unroll
   for (int jp = 0; jp < 2; ++jp) w2off[jp] = (uint32_t)(W1_BYTES + c16 * 128 + fc_swz<8>(c16, 4 * jp + g) * 16);
+
+  bf16x8 xf[2][KS1];
+  f32x4 acc2[2][NT2];
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+    for (int j = 0; j < NT2; ++j) acc2[rg][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // ---- acc2 += h (two 32-unit k-steps of this wave's rows, as fragments) x the W2-type image at img2 + W1_BYTES: model columns
+  //      16 j .. +15, units 0 .. 63 (read-ahead in groups of four output tiles; group q = k-step q / NG4, tiles 4 (q % NG4) .. + 3)
+  auto second_product = [&](uint32_t img2, bf16x8 (&h)[2][2]) {
+    constexpr int NG4 = NT2 / 4, NGRP = 2 * NG4;
+    bf16x8 wq[2][4];
+    auto read_w2 = [&](auto qc, bf16x8 (&dst)[4]) {
+      constexpr int q = decltype(qc)::value;
+      constexpr int jp = q / NG4, j0 = 4 * (q % NG4);
+      const uint32_t a0 = img2 + w2off[jp];
+      lds_read128<(j0 + 0) * 16 * 128>(dst[0], a0);
+      lds_read128<(j0 + 1) * 16 * 128>(dst[1], a0);
+      lds_read128<(j0 + 2) * 16 * 128>(dst[2], a0);
+      lds_read128<(j0 + 3) * 16 * 128>(dst[3], a0);
+    };
+    auto p2 = [&](auto self, auto qc) -> void {
+      constexpr int q = decltype(qc)::value;
+      if constexpr (q < NGRP) {
+        if constexpr (q + 1 < NGRP) { read_w2(std::integral_constant<int, q + 1>{}, wq[(q + 1) & 1]); FC_LGKM_WAIT(4); }
+        else FC_LGKM_WAIT(0);
+        constexpr int jp = q / NG4, j0 = 4 * (q % NG4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc2[0][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 1][t], h[0][jp], acc2[0][j0 + t], 0, 0, 0);
+          acc2[1][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 1][t], h[1][jp], acc2[1][j0 + t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        self(self, std::integral_constant<int, q + 1>{});
+      }
+    };
+    read_w2(std::integral_constant<int, 0>{}, wq[0]);
+    p2(p2, std::integral_constant<int, 0>{});
+  };
+
+  // ---- LayerNorm-backward tail: dX = acc2 + R, rounded to bf16 as the unfused data-gradient GEMM stored it, into a wave-private
+  //      LDS image; then ln_bwd_kernel's own arithmetic on it in LayerNorm's layout (a row = 8 lanes x NV 16-byte vectors): the
+  //      accumulators are released at once (doing the LayerNorm in the MFMA register layout -- 96 accumulators + the row's Z and
+  //      dX -- spilled ~80 registers at D = 192, and the allocator then also spilled loop-invariant fragments).
+  //      reload: dY goes back into the image and is re-read as the activation fragments xf of the product that follows.
+  constexpr int LDI = D;                                // image row (elements; unpadded: exactly four images per ring slot)
+  constexpr int IMG = 32 * LDI * 2;                     // bytes per wave: 12,288 | 8,192
+  static_assert(SLOT % IMG == 0 && FC_MAXW <= 2 * (SLOT / IMG), "whole wave images, seven of them in two ring slots");
+  auto ln_tail = [&](const bf16* Rp, const bf16* Zp, const float* meanp, const float* rstdp, const float* gammap, const IqRng& rngx,
+                     uint32_t thr, float dsc, bf16* dZp, bf16* dYp, bf16* img, float* wsp, auto reload_c) {
+    constexpr bool reload = decltype(reload_c)::value;
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg) {
+      const long gr = min(row0 + rg * 16 + c16, (long)p.M - 1);
+  #pragma unroll
+      for (int jp = 0; jp < NP2; ++jp) {
+        const int col = 32 * jp + (odd ? 16 + 4 * (g - 1) : 4 * g);
+        const bf16x8 res = *reinterpret_cast<const bf16x8*>(Rp + gr * D + col);
+        float w[8];
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float va = acc2[rg][2 * jp][r], vb = acc2[rg][2 * jp + 1][r];
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
+          w[r] = __uint_as_float(sw[0]);
+          w[4 + r] = __uint_as_float(sw[1]);
+        }
+  #pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] += (float)res[e];
+        *reinterpret_cast<bf16x8*>(img + (rg * 16 + c16) * LDI + col) = pack8(w);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // wave-private image: the wave's own LDS writes, no barrier
+    {
+      constexpr int LPR = 8, NV = D / (8 * LPR);          // 3 | 2
+      const int lj = lane & 7, rsub = lane >> 3;          // 8 rows per pass, 4 passes
+      const float invD = 1.0f / (float)D;
+      float gmm[NV][8], ag[NV][8], ab[NV][8];
+  #pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(gammap + (v * LPR + lj) * 8), b4 = *reinterpret_cast<const f32x4*>(gammap + (v * LPR + lj) * 8 + 4);
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) { gmm[v][e] = a4[e]; gmm[v][4 + e] = b4[e]; }
+  #pragma unroll
+        for (int e = 0; e < 8; ++e) { ag[v][e] = 0.f; ab[v][e] = 0.f; }
+      }
+  #pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int rl = it * 8 + rsub;
+        const long row = row0 + rl;
+        const bool ok = row < p.M;
+        const long gr = min(row, (long)p.M - 1);
+        const float mean = meanp[gr], rstd = rstdp[gr];
+        float xh[NV][8], dy[NV][8];
+        float s1 = 0.f, s2 = 0.f;
+  #pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          bf16x8 td = *reinterpret_cast<const bf16x8*>(img + rl * LDI + (v * LPR + lj) * 8);
+          bf16x8 tz = *reinterpret_cast<const bf16x8*>(Zp + gr * D + (v * LPR + lj) * 8);
+          if (!ok) { td = bf16x8{}; tz = bf16x8{}; }
+          unpack8(tz, xh[v]);
+          unpack8(td, dy[v]);
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            xh[v][e] = ok ? (xh[v][e] - mean) * rstd : 0.f;
+            ag[v][e] += dy[v][e] * xh[v][e];
+            ab[v][e] += dy[v][e];
+            dy[v][e] *= gmm[v][e];
+            s1 += dy[v][e];
+            s2 += dy[v][e] * xh[v][e];
+          }
+        }
+  #pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        const float c1 = s1 * invD, c2 = s2 * invD;
+        if (ok) {
+  #pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            float o[8];
+  #pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rstd * (dy[v][e] - c1 - xh[v][e] * c2);
+            const long off = row * D + (v * LPR + lj) * 8;
+            bf16x8 ob = pack8(o);
+            *reinterpret_cast<bf16x8*>(dZp + off) = ob;
+            if (DROP) {
+              const uint32_t keep = dropout_keep8(rngx, (uint64_t)off >> 3, thr);
+  #pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = ((keep >> e) & 1u) ? o[e] * dsc : 0.f;
+              ob = pack8(o);
+              *reinterpret_cast<bf16x8*>(dYp + off) = ob;
+            }
+            if (reload) *reinterpret_cast<bf16x8*>(img + rl * LDI + (v * LPR + lj) * 8) = ob;      // (where this lane read dX1 from)
+          }
+        }
+      }
+      if (reload) {                                       // dY rows as activation fragments (the dO fragments are dead)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  #pragma unroll
+        for (int rg = 0; rg < 2; ++rg)
+  #pragma unroll
+          for (int ks = 0; ks < KS1; ++ks)
+            xf[rg][ks] = *reinterpret_cast<const bf16x8*>(img + (rg * 16 + c16) * LDI + 32 * ks + 8 * fc_kperm(g));
+      }
+      // column sums over the wave's 32 rows: lanes with the same lj hold the same columns (8 row slots): fixed-order shuffles
+      float* prow = wsp;
+  #pragma unroll
+      for (int v = 0; v < NV; ++v) {
+  #pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float a = ag[v][e], b2 = ab[v][e];
+  #pragma unroll
+          for (int o = 8; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); b2 += __shfl_xor(b2, o, 64); }
+          ag[v][e] = a; ab[v][e] = b2;
+        }
+        if (rsub == 0) {
+          const int c = (v * LPR + lj) * 8;
+          *reinterpret_cast<f32x4*>(prow + c) = f32x4{ag[v][0], ag[v][1], ag[v][2], ag[v][3]};
+          *reinterpret_cast<f32x4*>(prow + c + 4) = f32x4{ag[v][4], ag[v][5], ag[v][6], ag[v][7]};
+          *reinterpret_cast<f32x4*>(prow + D + c) = f32x4{ab[v][0], ab[v][1], ab[v][2], ab[v][3]};
+          *reinterpret_cast<f32x4*>(prow + D + c + 4) = f32x4{ab[v][4], ab[v][5], ab[v][6], ab[v][7]};
+        }
+      }
+    }
+};
+  float* wsum = reinterpret_cast<float*>(smem + FC_NS * SLOT) + wave * (2 * D);      // [2 D]: this wave's column sums, behind the ring
+  auto reduce_partial = [&](float* dst) {                // one partial row per WORKGROUP: the waves' sums added in wave order
+    for (int i = tid; i < 2 * D; i += NW * 64) {         // (fixed: reproducible) -- seven times fewer rows for the slab reduce
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += reinterpret_cast<const float*>(smem + FC_NS * SLOT)[w * (2 * D) + i];
+      dst[(long)blockIdx.x * (2 * D) + i] = t;
+    }
+  };
+  // gate bits of chunk c for this lane's 4 x 8 hidden units: one dword, written by the forward kernel in exactly this wave /
+  // chunk / lane order.  Inline-asm load (invisible to the compiler's wait insertion: a tracked register-destination load in
+  // the loop would make it drain the ring), issued one chunk ahead, retired by the loop's own counted wait.
+  // (address = a wave-uniform base in scalar registers + a 32-bit lane offset, here and for the gH stores below: 64-bit per-lane
+  //  pointers live across the chunk loop were what the register allocator spilled -- and reloaded inside the loop)
+  const uint32_t* gate_wave = p.gate + (row0 >> 5) * nchunk * 64;
+  const uint32_t lane4 = (uint32_t)lane * 4u;
+  uint32_t gnext;
+  auto load_gate = [&](int c) {
+    const uint32_t* src = gate_wave + c * 64;           // wave-uniform
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(gnext) : "v"(lane4), "s"(src) : "memory");
+  };
+  const uint32_t gh_lane = (uint32_t)((c16 * F + (odd ? 16 + 4 * (g - 1) : 4 * g)) * 2);      // row c16, this lane's 8 units of a pair
+  const IqRng rng = DROP ? rng_resolve(p.rng) : p.rng;
+
+  if (PREB) {
+    // ---- first stage: acc2 = A0 W0t^T over K0 = 3 D in chunk pairs (slot = two W2-type images: columns 128 i .. +63 | +64 .. +127
+    //      of W0t's rows); the last pair of an odd chunk count is half empty ------------------------------------------------------
+    constexpr int K0 = 3 * D, NC0 = K0 / FC_CHUNK, NQ0 = (NC0 + 1) / 2;       // 9 chunks in 5 pairs | 6 in 3
+    auto issue_pre = [&](int i) {
+      unsigned char* slot = smem + (i % FC_NS) * SLOT;
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+#pragma unroll
+      for (int k = 0; k < PPW; ++k) {
+        const int pc = min(wave + k * NW, PIECES - 1);
+        const int h = pc >= W1_PIECES ? 1 : 0;
+        const int l2 = (pc - h * W1_PIECES) * 64 + ln;
+        const int r = l2 >> 3, sl = l2 & 7;
+        const int q = fc_swz<8>(r, sl);
+        const int col = min((2 * i + h) * FC_CHUNK, K0 - FC_CHUNK) + ((q & ~3) | fc_kperm(q & 3)) * 8;
+        const unsigned off = (unsigned)((r * K0 + col) * 2);
+        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(reinterpret_cast<const char*>(p.W0t) + off), (lds_void_t*)(slot + pc * 1024), 16, 0, 0);
+      }
+    };
+    // this wave's A0 rows of pair i as fragments [half][rg][k-step]: inline-asm loads (see load_gate), one pair ahead
+    bf16x8 aF[2][2][2][2];
+    auto load_a = [&](int i) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (2 * i + h >= NC0) break;
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp) {
+            const bf16* src = p.A0 + rowc[rg] * K0 + (2 * i + h) * FC_CHUNK + 32 * jp + 8 * fc_kperm(g);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(aF[i & 1][h][rg][jp]) : "v"(src) : "memory");
+          }
+      }
+    };
+    if (have) load_a(0);
+    issue_pre(0);
+    if (NQ0 > 1) issue_pre(1);
+    const IqRng rng0 = DROP ? rng_resolve(p.rng0) : p.rng0;
+#pragma unroll
+    for (int i = 0; i < NQ0; ++i) {
+      // queue, oldest first: pieces of pair i | fragments of pair i | pieces of pair i + 1: at most PPW outstanding = the first two landed
+      if (i == 0 || i + 1 >= NQ0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (have && i + 1 < NQ0) load_a(i + 1);
+      if (i + 2 < NQ0) issue_pre(i + 2);
+      if (!have) continue;
+      const uint32_t slot_addr = lds0 + (i % FC_NS) * SLOT;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (2 * i + h >= NC0) break;
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp) asm volatile("" : "+v"(aF[i & 1][h][rg][jp]));       // (landed: the wait above)
+        second_product(slot_addr + h * W1_BYTES - W1_BYTES, aF[i & 1][h]);
+      }
+    }
+    // every wave is done with the ring: the main loop's chunk 0 travels into slot 0 while the images of the tail sit in slots 1, 2
+    __syncthreads();
+    issue_chunk(0);
+    if (have) load_gate(0);
+    bf16* img0 = reinterpret_cast<bf16*>(smem + (wave < SLOT / IMG ? SLOT + wave * IMG : 2 * SLOT + (wave - SLOT / IMG) * IMG));
+    if (have) ln_tail(p.R0, p.Z0, p.mean0, p.rstd0, p.gamma0, rng0, p.thresh, p.dscale, p.dZ0, p.dY0, img0, wsum, std::true_type{});
+    else for (int i = lane; i < 2 * D; i += 64) wsum[i] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // chunk 0, the gate word, this stage's stores
+    __syncthreads();
+    if (nchunk > 1) issue_chunk(1);                      // (the images are dead)
+    reduce_partial(p.partial0);
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+      for (int j = 0; j < NT2; ++j) acc2[rg][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  } else {
+    issue_chunk(0);
+    if (nchunk > 1) issue_chunk(1);
+    // ---- this wave's dO rows as activation fragments; the gate rows of chunk 0 --------------------------------------------------
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks)
+        xf[rg][ks] = have ? *reinterpret_cast<const bf16x8*>(p.dO + rowc[rg] * D + 32 * ks + 8 * fc_kperm(g)) : bf16x8{};
+    load_gate(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg) {
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) asm volatile("" : "+v"(xf[rg][ks]));
+  }
+  asm volatile("" : "+v"(gnext));
 
   for (int c = 0; c < nchunk; ++c) {
     // Queue of this wave at this point, youngest first: the 4 gH stores of chunk c-1 | the gate load of chunk c | the ring
@@ -807,60 +1063,21 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
     asm volatile("" ::: "memory");
     if (c + 1 < nchunk) load_gate(c + 1);
 #pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
-      const int col = f0 + 32 * jp + (odd ? 16 + 4 * (g - 1) : 4 * g);
-#pragma unroll
-      for (int rg = 0; rg < 2; ++rg) {
-        const long grow = row0 + rg * 16 + c16;
-        if (grow < p.M) *reinterpret_cast<bf16x8*>(p.gH + grow * F + col) = hf[rg][jp];
+    for (int rg = 0; rg < 2; ++rg) {
+      const bf16* base = p.gH + (row0 + rg * 16) * F + f0;          // wave-uniform
+      if (row0 + rg * 16 + c16 < p.M) {
+        asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(gh_lane), "v"(hf[rg][0]), "s"(base) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, %2 offset:64" :: "v"(gh_lane), "v"(hf[rg][1]), "s"(base) : "memory");
       }
     }
     // ---- second product: acc2 += gH_c x W1t rows (model columns) 16 j .. +15, hidden units f0 .. f0 + 63 --------------------------
-    constexpr int NG4 = NT2 / 4, NGRP = 2 * NG4;
-    bf16x8 wq[2][4];
-    auto read_w2 = [&](auto qc, bf16x8 (&dst)[4]) {
-      constexpr int q = decltype(qc)::value;
-      constexpr int jp = q / NG4, j0 = 4 * (q % NG4);
-      const uint32_t a0 = slot_addr + w2off[jp];
-      lds_read128<(j0 + 0) * 16 * 128>(dst[0], a0);
-      lds_read128<(j0 + 1) * 16 * 128>(dst[1], a0);
-      lds_read128<(j0 + 2) * 16 * 128>(dst[2], a0);
-      lds_read128<(j0 + 3) * 16 * 128>(dst[3], a0);
-    };
-    auto p2 = [&](auto self, auto qc) -> void {
-      constexpr int q = decltype(qc)::value;
-      if constexpr (q < NGRP) {
-        if constexpr (q + 1 < NGRP) { read_w2(std::integral_constant<int, q + 1>{}, wq[(q + 1) & 1]); FC_LGKM_WAIT(4); }
-        else FC_LGKM_WAIT(0);
-        constexpr int jp = q / NG4, j0 = 4 * (q % NG4);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          acc2[0][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 1][t], hf[0][jp], acc2[0][j0 + t], 0, 0, 0);
-          acc2[1][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 1][t], hf[1][jp], acc2[1][j0 + t], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        self(self, std::integral_constant<int, q + 1>{});
-      }
-    };
-    read_w2(std::integral_constant<int, 0>{}, wq[0]);
-    p2(p2, std::integral_constant<int, 0>{});
+    second_product(slot_addr, hf);
   }
-  // ---- tail: dX1 = acc2 + R, rounded to bf16 as the unfused data-gradient GEMM stored it, into a wave-private LDS image; then
-  //      ln_bwd_kernel's own arithmetic on it in LayerNorm's layout (a row = 8 lanes x NV 16-byte vectors): the accumulators are
-  //      released at once (doing the LayerNorm in the MFMA register layout -- 96 accumulators + the row's Z and dX -- spilled
-  //      ~80 registers at D = 192, and the allocator then also spilled loop-invariant fragments).  Scratch = the ring slots of
-  //      chunks nchunk-2 and nchunk-3: every wave is past the last hand-over barrier, nobody reads or fills them any more.
-  constexpr int LDI = D;                                // image row (elements; unpadded: exactly four images per ring slot)
-  constexpr int IMG = 32 * LDI * 2;                     // bytes per wave: 12,288 | 8,192
-  static_assert(SLOT % IMG == 0 && FC_MAXW <= 2 * (SLOT / IMG), "whole wave images, seven of them in the two dead ring slots");
-  bf16* img;
+  // ---- tail: norm1 backward on dX1 = acc2 + R.  Image scratch = the ring slots of chunks nchunk-2 and nchunk-3: every wave is past
+  //      the last hand-over barrier, nobody reads or fills them any more. ----------------------------------------------------------
   const int sC = (nchunk - 1) % FC_NS;                  // the last chunk's slot (slower waves may still be reading it)
   const int s2 = (sC + 2) % FC_NS, s3 = (sC + 1) % FC_NS;
-  {
-    const int per = SLOT / IMG;                         // whole images per slot
-    img = reinterpret_cast<bf16*>(smem + (wave < per ? s2 * SLOT + wave * IMG : s3 * SLOT + (wave - per) * IMG));
-  }
-  float* wsum = reinterpret_cast<float*>(smem + FC_NS * SLOT) + wave * (2 * D);      // [2 D]: this wave's column sums, behind the ring
+  bf16* img = reinterpret_cast<bf16*>(smem + (wave < SLOT / IMG ? s2 * SLOT + wave * IMG : s3 * SLOT + (wave - SLOT / IMG) * IMG));
   constexpr int NB0 = D / FC_CHUNK;                     // 64-row blocks of the transposed projection weight: 3 | 2
   auto issue_wot = [&](int b0, int nb, unsigned char* dst) {       // blocks b0 .. b0 + nb - 1 as W1-type images at dst
     const int pieces = nb * W1_PIECES;
@@ -876,132 +1093,12 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
     __syncthreads();                                    // every wave has left the loop: the last chunk's slot is free
     issue_wot(0, 2, smem + sC * SLOT);                  // (in flight under the LayerNorm backward below)
   }
-  if (have) {
-#pragma unroll
-  for (int rg = 0; rg < 2; ++rg) {
-    const long gr = min(row0 + rg * 16 + c16, (long)p.M - 1);
-#pragma unroll
-    for (int jp = 0; jp < NP2; ++jp) {
-      const int col = 32 * jp + (odd ? 16 + 4 * (g - 1) : 4 * g);
-      const bf16x8 res = *reinterpret_cast<const bf16x8*>(p.R + gr * D + col);
-      float w[8];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float va = acc2[rg][2 * jp][r], vb = acc2[rg][2 * jp + 1][r];
-        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
-        w[r] = __uint_as_float(sw[0]);
-        w[4 + r] = __uint_as_float(sw[1]);
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) w[e] += (float)res[e];
-      *reinterpret_cast<bf16x8*>(img + (rg * 16 + c16) * LDI + col) = pack8(w);
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // wave-private image: the wave's own LDS writes, no barrier
-  {
-    constexpr int LPR = 8, NV = D / (8 * LPR);          // 3 | 2
-    const int lj = lane & 7, rsub = lane >> 3;          // 8 rows per pass, 4 passes
-    const float invD = 1.0f / (float)D;
-    float gmm[NV][8], ag[NV][8], ab[NV][8];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.gamma + (v * LPR + lj) * 8), b4 = *reinterpret_cast<const f32x4*>(p.gamma + (v * LPR + lj) * 8 + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { gmm[v][e] = a4[e]; gmm[v][4 + e] = b4[e]; }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { ag[v][e] = 0.f; ab[v][e] = 0.f; }
-    }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int rl = it * 8 + rsub;
-      const long row = row0 + rl;
-      const bool ok = row < p.M;
-      const long gr = min(row, (long)p.M - 1);
-      const float mean = p.mean[gr], rstd = p.rstd[gr];
-      float xh[NV][8], dy[NV][8];
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        bf16x8 td = *reinterpret_cast<const bf16x8*>(img + rl * LDI + (v * LPR + lj) * 8);
-        bf16x8 tz = *reinterpret_cast<const bf16x8*>(p.Z1 + gr * D + (v * LPR + lj) * 8);
-        if (!ok) { td = bf16x8{}; tz = bf16x8{}; }
-        unpack8(tz, xh[v]);
-        unpack8(td, dy[v]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          xh[v][e] = ok ? (xh[v][e] - mean) * rstd : 0.f;
-          ag[v][e] += dy[v][e] * xh[v][e];
-          ab[v][e] += dy[v][e];
-          dy[v][e] *= gmm[v][e];
-          s1 += dy[v][e];
-          s2 += dy[v][e] * xh[v][e];
-        }
-      }
-#pragma unroll
-      for (int o = LPR / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-      const float c1 = s1 * invD, c2 = s2 * invD;
-      if (ok) {
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          float o[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = rstd * (dy[v][e] - c1 - xh[v][e] * c2);
-          const long off = row * D + (v * LPR + lj) * 8;
-          bf16x8 ob = pack8(o);
-          *reinterpret_cast<bf16x8*>(p.dZ + off) = ob;
-          if (DROP) {
-            const uint32_t keep = dropout_keep8(rng, (uint64_t)off >> 3, p.thresh);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = ((keep >> e) & 1u) ? o[e] * p.dscale : 0.f;
-            ob = pack8(o);
-            *reinterpret_cast<bf16x8*>(p.dY + off) = ob;
-          }
-          if (POSTB) *reinterpret_cast<bf16x8*>(img + rl * LDI + (v * LPR + lj) * 8) = ob;      // (where this lane read dX1 from)
-        }
-      }
-    }
-    if (POSTB) {                                        // dY rows as activation fragments (the dO fragments are dead)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int rg = 0; rg < 2; ++rg)
-#pragma unroll
-        for (int ks = 0; ks < KS1; ++ks)
-          xf[rg][ks] = *reinterpret_cast<const bf16x8*>(img + (rg * 16 + c16) * LDI + 32 * ks + 8 * fc_kperm(g));
-    }
-    // column sums over the wave's 32 rows: lanes with the same lj hold the same columns (8 row slots): fixed-order shuffles
-    float* prow = wsum;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float a = ag[v][e], b2 = ab[v][e];
-#pragma unroll
-        for (int o = 8; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); b2 += __shfl_xor(b2, o, 64); }
-        ag[v][e] = a; ab[v][e] = b2;
-      }
-      if (rsub == 0) {
-        const int c = (v * LPR + lj) * 8;
-        *reinterpret_cast<f32x4*>(prow + c) = f32x4{ag[v][0], ag[v][1], ag[v][2], ag[v][3]};
-        *reinterpret_cast<f32x4*>(prow + c + 4) = f32x4{ag[v][4], ag[v][5], ag[v][6], ag[v][7]};
-        *reinterpret_cast<f32x4*>(prow + D + c) = f32x4{ab[v][0], ab[v][1], ab[v][2], ab[v][3]};
-        *reinterpret_cast<f32x4*>(prow + D + c + 4) = f32x4{ab[v][4], ab[v][5], ab[v][6], ab[v][7]};
-      }
-    }
-  }
-  } else {
-    for (int i = lane; i < 2 * D; i += 64) wsum[i] = 0.f;           // a wave without rows contributes zeros
-  }
-  // one partial row per WORKGROUP: the waves' sums added in wave order (fixed: reproducible) -- seven times fewer rows for the
-  // layer's slab reduce than one per wave
+  if (have) ln_tail(p.R, p.Z1, p.mean, p.rstd, p.gamma, rng, p.thresh, p.dscale, p.dZ, p.dY, img, wsum, std::integral_constant<bool, POSTB>{});
+  else for (int i = lane; i < 2 * D; i += 64) wsum[i] = 0.f;           // a wave without rows contributes zeros
   if (POSTB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of weight blocks 0 and 1 (and its stores)
   __syncthreads();
   if (POSTB && NB0 > 2) issue_wot(2, NB0 - 2, smem + s2 * SLOT);    // (the images are dead now)
-  for (int i = tid; i < 2 * D; i += NW * 64) {
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) t += reinterpret_cast<const float*>(smem + FC_NS * SLOT)[w * (2 * D) + i];
-    p.partial[(long)blockIdx.x * (2 * D) + i] = t;
-  }
+  reduce_partial(p.partial);
   if (!POSTB) return;
   // ---- POSTB: dA = dY Wot^T, 64 output columns (one weight block) at a time ----------------------------------------------------
 #pragma unroll
@@ -1053,13 +1150,11 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
   }
 }
 
-// waves per workgroup: 32 rows each; one workgroup per CU (the ring is most of a CU's LDS), so as many waves as it takes to
-// cover M with <= 256 workgroups -- of the instantiated counts {2, 4, 7}
-inline int chain_waves(int M) {
-  const long units = ((long)M + 31) / 32;
-  const long nw = (units + 255) / 256;
-  return nw <= 2 ? 2 : nw <= 4 ? 4 : FC_MAXW;
-}
+// waves per workgroup: 32 rows each; one workgroup per CU (the ring is most of a CU's LDS).  Seven waves cover cfg B's 50,432 rows
+// with 226 workgroups; fewer rows simply leave CUs or waves idle (the training plan takes these kernels only above 32,768 rows:
+// builds with 2 and 4 waves per workgroup existed for smaller M, were never faster than the tiled GEMMs there, and -- 24 DMA
+// pieces per wave instead of 7 -- spilled up to 176 scalar and 75 vector registers)
+inline int chain_waves(int M) { (void)M; return FC_MAXW; }
 
 template <int D, int NW>
 int launch_chain(const FfnChainParams& p, hipStream_t st) {
@@ -1081,13 +1176,7 @@ int launch_chain(const FfnChainParams& p, hipStream_t st) {
   return iq_launch_status();
 }
 template <int D>
-int launch_chain_d(const FfnChainParams& p, hipStream_t st) {
-  switch (chain_waves(p.M)) {
-    case 2: return launch_chain<D, 2>(p, st);
-    case 4: return launch_chain<D, 4>(p, st);
-    default: return launch_chain<D, FC_MAXW>(p, st);
-  }
-}
+int launch_chain_d(const FfnChainParams& p, hipStream_t st) { return launch_chain<D, FC_MAXW>(p, st); }
 
 template <int D, int NW>
 int launch_chain_bwd(const FfnChainBwdParams& p, hipStream_t st) {
@@ -1095,26 +1184,21 @@ int launch_chain_bwd(const FfnChainBwdParams& p, hipStream_t st) {
   const size_t lds = (size_t)FC_NS * SLOT + (size_t)NW * 2 * D * sizeof(float);     // ring + the waves' gamma / beta column sums
   const long units = ((long)p.M + 31) / 32;
   const int grid = (int)((units + NW - 1) / NW);
-#define FC_LAUNCHB(DROP_, POST_)                                                                                              \
+#define FC_LAUNCHB(DROP_, MODE_)                                                                                              \
   do {                                                                                                                        \
-    auto k = ffn_chain_bwd_kernel<D, NW, DROP_, POST_>;                                                                       \
+    auto k = ffn_chain_bwd_kernel<D, NW, DROP_, MODE_>;                                                                       \
     static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     (void)attr;                                                                                                               \
     k<<<grid, NW * 64, lds, st>>>(p);                                                                                         \
   } while (0)
-  if (p.Wot) { if (p.drop_on) FC_LAUNCHB(true, true); else FC_LAUNCHB(false, true); }
-  else { if (p.drop_on) FC_LAUNCHB(true, false); else FC_LAUNCHB(false, false); }
+  if (p.A0) { if (p.drop_on) FC_LAUNCHB(true, 2); else FC_LAUNCHB(false, 2); }
+  else if (p.Wot) { if (p.drop_on) FC_LAUNCHB(true, 1); else FC_LAUNCHB(false, 1); }
+  else { if (p.drop_on) FC_LAUNCHB(true, 0); else FC_LAUNCHB(false, 0); }
 #undef FC_LAUNCHB
   return iq_launch_status();
 }
 template <int D>
-int launch_chain_bwd_d(const FfnChainBwdParams& p, hipStream_t st) {
-  switch (chain_waves(p.M)) {
-    case 2: return launch_chain_bwd<D, 2>(p, st);
-    case 4: return launch_chain_bwd<D, 4>(p, st);
-    default: return launch_chain_bwd<D, FC_MAXW>(p, st);
-  }
-}
+int launch_chain_bwd_d(const FfnChainBwdParams& p, hipStream_t st) { return launch_chain_bwd<D, FC_MAXW>(p, st); }
 
 }  // namespace
 
@@ -1216,13 +1300,18 @@ extern "C" size_t iq_ffn_chain_gate_bytes(int M, int F) {
   return (size_t)((M + 31) / 32) * (size_t)(F / FC_CHUNK) * 64 * sizeof(uint32_t);
 }
 
-extern "C" int iq_ffn_chain_bwd(const void* dO, const void* W2t, const void* gate_bits, float gate_scale, void* gH, const void* W1t,
-                                const void* residual, const void* z1, const float* mean, const float* rstd, const float* gamma,
-                                const iq_dropout_t* drop, void* dz, void* dy, float* partial, const void* Wot, void* dA, int frames,
-                                int S, int D, int F, iq_stream_t stream) {
+namespace {
+struct ChainBwdPre {                                     // the optional first stage's operands (iq_qkv_dgrad_ffn_chain_bwd)
+  const void* A0; const void* W0t; const void* R0; const void* Z0; const float* mean0; const float* rstd0; const float* gamma0;
+  const iq_dropout_t* drop0; void* dZ0; void* dY0; float* partial0;
+};
+
+int chain_bwd(const ChainBwdPre* pre, const void* dO, const void* W2t, const void* gate_bits, float gate_scale, void* gH, const void* W1t,
+              const void* residual, const void* z1, const float* mean, const float* rstd, const float* gamma, const iq_dropout_t* drop,
+              void* dz, void* dy, float* partial, const void* Wot, void* dA, int frames, int S, int D, int F, iq_stream_t stream) {
   if (frames <= 0) return IQ_OK;
   if ((Wot == nullptr) != (dA == nullptr) || ((uintptr_t)Wot | (uintptr_t)dA) % 16) return IQ_ERR_ARG;
-  if (!dO || !W2t || !gate_bits || !gH || !W1t || !residual || !z1 || !mean || !rstd || !gamma || !dz || !partial) return IQ_ERR_ARG;
+  if ((!pre && !dO) || !W2t || !gate_bits || !gH || !W1t || !residual || !z1 || !mean || !rstd || !gamma || !dz || !partial) return IQ_ERR_ARG;
   if (!iq_ffn_chain_supported(S, D, F)) return IQ_ERR_UNSUPPORTED;
   if (((uintptr_t)dO | (uintptr_t)W2t | (uintptr_t)W1t | (uintptr_t)gate_bits | (uintptr_t)gH | (uintptr_t)residual | (uintptr_t)z1 |
        (uintptr_t)dz | (uintptr_t)dy | (uintptr_t)gamma | (uintptr_t)partial) % 16) return IQ_ERR_ARG;
@@ -1241,11 +1330,52 @@ extern "C" int iq_ffn_chain_bwd(const void* dO, const void* W2t, const void* gat
     p.thresh = dropout_thresh(drop->p);
     p.dscale = dropout_scale(drop->p);
   }
+  if (pre) {
+    if (!Wot) return IQ_ERR_ARG;                        // (built with the last stage only)
+    if (!pre->A0 || !pre->W0t || !pre->R0 || !pre->Z0 || !pre->mean0 || !pre->rstd0 || !pre->gamma0 || !pre->dZ0 || !pre->partial0)
+      return IQ_ERR_ARG;
+    if (((uintptr_t)pre->A0 | (uintptr_t)pre->W0t | (uintptr_t)pre->R0 | (uintptr_t)pre->Z0 | (uintptr_t)pre->gamma0 |
+         (uintptr_t)pre->dZ0 | (uintptr_t)pre->dY0 | (uintptr_t)pre->partial0) % 16) return IQ_ERR_ARG;
+    const float p0 = pre->drop0 ? pre->drop0->p : 0.f, p1 = drop ? drop->p : 0.f;
+    if (p0 != p1 || (p.drop_on && !pre->dY0)) return IQ_ERR_ARG;          // one dropout probability per layer (encoder_layer.py:13-21)
+    p.A0 = (const bf16*)pre->A0; p.W0t = (const bf16*)pre->W0t; p.R0 = (const bf16*)pre->R0; p.Z0 = (const bf16*)pre->Z0;
+    p.mean0 = pre->mean0; p.rstd0 = pre->rstd0; p.gamma0 = pre->gamma0;
+    p.dZ0 = (bf16*)pre->dZ0; p.dY0 = (bf16*)pre->dY0; p.partial0 = pre->partial0;
+    if (p.drop_on) { p.rng0.seed = pre->drop0->seed; p.rng0.step = pre->drop0->step; p.rng0.site = pre->drop0->site; p.rng0.step_dev = pre->drop0->step_dev; }
+  }
   hipStream_t st = (hipStream_t)stream;
   IQ_PROF(IQ_FAM_GEMM_NT, st);
   const double M = (double)p.M;
-  IQ_PROF_K(2.0 * (M * D * (4 + (p.drop_on ? 1 : 0) + (Wot ? 1 : 0)) + 2.0 * M * F + 2.0 * D * F + (Wot ? (double)D * D : 0.0)) + 8.0 * M,
-            4.0 * M * D * F + (Wot ? 2.0 * M * D * D : 0.0), "ffn_chain_bwd_kernel<%d, %d, %s, %s>", D, chain_waves(p.M),
-            p.drop_on ? "true" : "false", Wot ? "true" : "false");
+  double bytes = 2.0 * (M * D * (4 + (p.drop_on ? 1 : 0) + (Wot ? 1 : 0)) + 2.0 * M * F + 2.0 * D * F + (Wot ? (double)D * D : 0.0)) + 8.0 * M;
+  double flops = 4.0 * M * D * F + (Wot ? 2.0 * M * D * D : 0.0);
+  if (pre) {      // A0 [M,3D], R0 / Z0 in, dZ0 (+ dY0) out, W0t; dO itself is no longer read
+    bytes += 2.0 * (M * 3 * D + M * D * (3 + (p.drop_on ? 1 : 0) - 1) + 3.0 * D * D) + 8.0 * M;
+    flops += 6.0 * M * D * D;
+  }
+  IQ_PROF_K(bytes, flops, "ffn_chain_bwd_kernel<%d, %d, %s, %d>", D, chain_waves(p.M), p.drop_on ? "true" : "false", pre ? 2 : Wot ? 1 : 0);
   return D == 192 ? launch_chain_bwd_d<192>(p, st) : launch_chain_bwd_d<128>(p, st);
+}
+}  // namespace
+
+extern "C" int iq_ffn_chain_bwd(const void* dO, const void* W2t, const void* gate_bits, float gate_scale, void* gH, const void* W1t,
+                                const void* residual, const void* z1, const float* mean, const float* rstd, const float* gamma,
+                                const iq_dropout_t* drop, void* dz, void* dy, float* partial, const void* Wot, void* dA, int frames,
+                                int S, int D, int F, iq_stream_t stream) {
+  return chain_bwd(nullptr, dO, W2t, gate_bits, gate_scale, gH, W1t, residual, z1, mean, rstd, gamma, drop, dz, dy, partial, Wot, dA,
+                   frames, S, D, F, stream);
+}
+
+// iq_ffn_chain_bwd with the launch that would produce its dO in front: dX2 = gQKV[M,3D] * Wqkv_t[D,3D]^T + residual0 (the q,k,v
+// projection's data gradient of the layer above + the residual path), norm2 backward on it (z2 / mean2 / rstd2 / gamma2, dropout
+// site drop2): dz2, dy2 (this layer's dO; dz2 where there is no dropout) and partial2 are written as iq_gemm_bf16_lnbwd writes
+// them; `residual` of the second stage is normally dz2 itself (each wave re-reads the rows it wrote).
+extern "C" int iq_qkv_dgrad_ffn_chain_bwd(const void* gQKV, const void* Wqkv_t, const void* residual0, const void* z2, const float* mean2,
+                                          const float* rstd2, const float* gamma2, const iq_dropout_t* drop2, void* dz2, void* dy2,
+                                          float* partial2, const void* W2t, const void* gate_bits, float gate_scale, void* gH,
+                                          const void* W1t, const void* residual, const void* z1, const float* mean, const float* rstd,
+                                          const float* gamma, const iq_dropout_t* drop, void* dz, void* dy, float* partial, const void* Wot,
+                                          void* dA, int frames, int S, int D, int F, iq_stream_t stream) {
+  const ChainBwdPre pre = {gQKV, Wqkv_t, residual0, z2, mean2, rstd2, gamma2, drop2, dz2, dy2, partial2};
+  return chain_bwd(&pre, nullptr, W2t, gate_bits, gate_scale, gH, W1t, residual, z1, mean, rstd, gamma, drop, dz, dy, partial, Wot, dA,
+                   frames, S, D, F, stream);
 }

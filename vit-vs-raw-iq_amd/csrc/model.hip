@@ -257,7 +257,10 @@ inline bool use_ffn_chain(int M, int S, int D, int F) {
 }
 
 // ... with the attention output projection + norm1 as its first stage (IQ_TUNE_CHAIN_PRE=0: the projection stays a launch of its own)
-// and the next layer's q,k,v projection as its last (2, default; 1: without)
+// and the next layer's q,k,v projection as its last, the backward launch with the output projection's data gradient behind it
+// (2, default; 1: without).  3: the backward launch also takes the q,k,v data gradient of the layer above + norm2 backward in
+// front (iq_qkv_dgrad_ffn_chain_bwd) -- measured equal, 108.5 us against 68.1 + 39.6 for cfg B, step 4.896 vs 4.876 ms: that stage
+// moves 134 MB for 11 GFLOP and every workgroup runs it at the same time, so it is as HBM-bound inside the launch as outside it.
 inline int use_chain_pre() {
   static const int tune = [] { const char* e = getenv("IQ_TUNE_CHAIN_PRE"); return e ? atoi(e) : 2; }();
   return tune;
@@ -617,6 +620,7 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
   // whole rows (D = 128 | 192): norm1's in the FFN1 data gradient of the same layer, norm2's in the QKV data gradient of
   // the layer ABOVE (the top layer's comes from the head and keeps the stand-alone kernel).
   const bool fuse1 = iq_gemm_lnbwd_supported(D, F) != 0, fuse2 = iq_gemm_lnbwd_supported(D, 3 * D) != 0;
+  bool deferred = false;      // the layer above left its q,k,v data gradient + this layer's norm2 backward to this layer's chain launch
   for (int sidx = (stage_hi > Lr ? Lr : stage_hi); sidx >= 1 && sidx >= stage_lo; --sidx) {
     const int l = sidx - 1;
     const LayerOff& o = m->L[l];
@@ -642,7 +646,7 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
         {dAo, D, ws + a.att, D, G + o.wo, G + o.bo, D, D},            // attention.w_concat
         {gQKV, 3 * D, xin, D, G + o.wqkv, G + o.bqkv, 3 * D, D}};     // attention.w_q|w_k|w_v
     // the LayerNorm gamma/beta partial rows of this layer ride on the same reduce launch
-    const int rows2 = norm2_here ? iq_ln_bwd_partial_rows(M, D) : iq_gemm_lnbwd_partial_rows(M);
+    const int rows2 = norm2_here ? iq_ln_bwd_partial_rows(M, D) : deferred ? iq_ffn_chain_bwd_partial_rows(M) : iq_gemm_lnbwd_partial_rows(M);
     // the one-launch feed-forward backward (ffn_chain.hip) where the forward ran its one-launch counterpart (it left the gate bits)
     const bool chain = fuse1 && m->last_train_fwd && use_ffn_chain(M, S, D, F);
     const int rows1 = chain ? iq_ffn_chain_bwd_partial_rows(M) : fuse1 ? iq_gemm_lnbwd_partial_rows(M) : iq_ln_bwd_partial_rows(M, D);
@@ -650,7 +654,15 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
                                       {lp1, rows1, 2L * D, G + o.g1, D}, {lp1 + D, rows1, 2L * D, G + o.be1, D}};
     const iq_dropout_t dr1 = m->bwd_site(1 + 3 * l, step_dev, tr);
     const bool post = chain && use_chain_pre() >= 2;       // ... and the output projection's data gradient behind it
-    if (chain) {
+    if (chain && deferred) {
+      const LayerOff& ou = m->L[l + 1];
+      const iq_dropout_t dr2b = m->bwd_site(3 + 3 * l, step_dev, tr);
+      IQ_TRY(iq_qkv_dgrad_ffn_chain_bwd(gQKV, m->sht(ou.t_wqkv), gZ1, ws + a.z2, (const float*)(ws + a.mean2), (const float*)(ws + a.rstd2),
+                                        P + o.g2, &dr2b, gZ, gY, lp2, m->sht(o.t_w2), ws + a.gate, dscale, gH, m->sht(o.t_w1), gZ, ws + a.z1,
+                                        (const float*)(ws + a.mean1), (const float*)(ws + a.rstd1), P + o.g1, &dr1, gZ1, gY1, lp1,
+                                        m->sht(o.t_wo), ws + w.gAtt, B, S, D, F, stream),
+             "qkv dgrad of the layer above + norm2 bwd + ffn chain bwd + norm1 bwd + out-proj dgrad");
+    } else if (chain) {
       IQ_TRY(iq_ffn_chain_bwd(dO2, m->sht(o.t_w2), ws + a.gate, dscale, gH, m->sht(o.t_w1), gZ, ws + a.z1, (const float*)(ws + a.mean1),
                               (const float*)(ws + a.rstd1), P + o.g1, &dr1, gZ1, gY1, lp1, post ? m->sht(o.t_wo) : nullptr,
                               post ? ws + w.gAtt : nullptr, B, S, D, F, stream), "ffn chain bwd + norm1 bwd (+ out-proj dgrad)");
@@ -675,6 +687,9 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
     // The four weight gradients of the layer, BEFORE the QKV data gradient: fused with the norm2 backward of the layer
     // below, that GEMM overwrites gZ / gY and the norm2 partial rows, which the weight gradients / their reduce still read.
     IQ_TRY(iq_gemm_bf16_wgrad_grouped(wg, 4, M, wws, w.wgrad_ws_bytes, accumulate, 0, lnseg, 4, stream), "layer weight gradients");
+    // ... unless the layer below takes it into its own chain launch (iq_qkv_dgrad_ffn_chain_bwd)
+    deferred = l > 0 && fuse2 && chain && post && use_chain_pre() >= 3 && sidx - 1 >= stage_lo;
+    if (deferred) continue;
     if (l > 0 && fuse2) {
       const LayerOff& ob = m->L[l - 1];
       const WsPlan::L& ab = w.layers[l - 1];
