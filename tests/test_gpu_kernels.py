@@ -331,7 +331,7 @@ def _epi(N, **kw):
 @pytest.mark.parametrize("frames,S,D,F,pdrop", [(256, 197, 192, 768, 0.1), (7, 197, 192, 768, 0.0), (256, 65, 128, 1024, 0.2),
                                                  (5, 5, 128, 512, 0.0), (3, 224, 192, 128, 0.3), (9, 17, 128, 256, 0.1),
                                                  (4, 129, 128, 512, 0.0), (2, 1, 192, 256, 0.0), (100, 197, 192, 64, 0.1),
-                                                 (40, 197, 192, 192, 0.1)])
+                                                 (40, 197, 192, 192, 0.1), (520, 65, 128, 1024, 0.2), (400, 65, 128, 512, 0.0)])
 def test_ffn_chain_equals_ffn1_then_ffn2_layernorm(L, frames, S, D, F, pdrop):
     """iq_ffn_chain_fwd (the whole feed-forward sub-layer + norm2 of a frame in one workgroup: position_wise_feed_forward.py:12-17,
     encoder_layer.py:30-33) against the two launches it replaces -- iq_gemm_bf16_nt (bias, ReLU, dropout1) then iq_gemm_bf16_ln:
@@ -397,7 +397,7 @@ def test_ffn_chain_equals_ffn1_then_ffn2_layernorm(L, frames, S, D, F, pdrop):
 @pytest.mark.parametrize("with_qkv", [False, True])
 @pytest.mark.parametrize("frames,S,D,F,pdrop", [(256, 197, 192, 768, 0.1), (7, 197, 192, 832, 0.0), (256, 65, 128, 1024, 0.2),
                                                  (5, 5, 128, 512, 0.0), (40, 197, 192, 64, 0.1), (2, 1, 192, 256, 0.0),
-                                                 (130, 65, 128, 128, 0.1)])
+                                                 (130, 65, 128, 128, 0.1), (520, 65, 128, 1024, 0.2), (400, 65, 128, 512, 0.0)])
 def test_attn_out_ffn_chain_equals_gemm_ln_then_ffn_chain(L, frames, S, D, F, pdrop, with_qkv):
     """iq_attn_out_ffn_chain_fwd (encoder_layer.py:24-33 from the attention output on, one launch) against the two launches it
     replaces: its first stage (output projection + dropout + residual + norm1) against iq_gemm_bf16_ln -- equal except at
@@ -465,13 +465,15 @@ def test_attn_out_ffn_chain_equals_gemm_ln_then_ffn_chain(L, frames, S, D, F, pd
                                gate2.data_ptr(), frames, S, D, F, stream()), "ffn_chain")
     assert torch.equal(H.view(torch.int16), H2.view(torch.int16)) and torch.equal(Z2.view(torch.int16), Z22.view(torch.int16))
     assert torch.equal(X.view(torch.int16), X2.view(torch.int16)) and torch.equal(m2, m22) and torch.equal(r2, r22)
-    full = (M // 32) * (F // 64) * 64                  # (bits of rows past M, in the last wave's ragged unit, are never read)
+    rw = 32 if M > 32768 else 16                       # rows per wave (ffn_chain.hip::chain_shape)
+    full = (M // rw) * (F // 64) * 64                  # (bits of rows past M, in the last wave's ragged unit, are never read)
     assert torch.equal(gate[:full], gate2[:full])
 
 
 @pytest.mark.parametrize("frames,S,D,F,pdrop", [(256, 197, 192, 768, 0.1), (7, 197, 192, 832, 0.0), (256, 65, 128, 1024, 0.2),
                                                  (5, 5, 128, 512, 0.0), (3, 224, 192, 128, 0.3), (9, 17, 128, 896, 0.1),
-                                                 (40, 197, 192, 64, 0.1), (2, 1, 192, 256, 0.0)])
+                                                 (40, 197, 192, 64, 0.1), (2, 1, 192, 256, 0.0), (520, 65, 128, 1024, 0.2),
+                                                 (400, 65, 128, 512, 0.0)])
 @pytest.mark.parametrize("with_dA", [False, True])
 def test_ffn_chain_backward_equals_gate_gemm_then_dgrad_layernorm_backward(L, frames, S, D, F, pdrop, with_dA):
     """iq_ffn_chain_bwd (gate data gradient + FFN1 data gradient + residual + norm1 backward in one launch, gate = the "H > 0"
@@ -514,8 +516,10 @@ def test_ffn_chain_backward_equals_gate_gemm_then_dgrad_layernorm_backward(L, fr
     nan = float("nan")
     gH1 = torch.full((M, F), nan, dtype=torch.bfloat16, device=dev()); dz1 = torch.full_like(z, nan); dy1 = torch.zeros_like(z)
     rows = L.iq_ffn_chain_bwd_partial_rows(M)
-    units = (M + 31) // 32
-    assert rows == (units + 6) // 7                          # one row per workgroup of 7 waves
+    # one row per workgroup: 7 waves of 32 rows above 32,768 rows, 8 | 5 waves of 16 rows below (ffn_chain.hip::chain_shape)
+    rw, nw = (32, 7) if M > 32768 else (16, 8) if M > 20480 else (16, 5)
+    units = (M + rw - 1) // rw
+    assert rows == (units + nw - 1) // nw
     part1 = torch.full((rows, 2 * D), nan, device=dev())
     Wot = bf(torch.randn(D, D, device=dev(), generator=g) / math.sqrt(D))
     dA = torch.full((M, D), nan, dtype=torch.bfloat16, device=dev())
@@ -547,7 +551,8 @@ def test_ffn_chain_backward_equals_gate_gemm_then_dgrad_layernorm_backward(L, fr
 
 
 @pytest.mark.parametrize("frames,S,D,F,pdrop", [(256, 197, 192, 768, 0.1), (7, 197, 192, 832, 0.0), (256, 65, 128, 1024, 0.2),
-                                                 (5, 5, 128, 512, 0.0), (40, 197, 192, 64, 0.1), (2, 1, 192, 128, 0.0), (9, 17, 128, 896, 0.1)])
+                                                 (5, 5, 128, 512, 0.0), (40, 197, 192, 64, 0.1), (2, 1, 192, 128, 0.0), (9, 17, 128, 896, 0.1),
+                                                 (520, 65, 128, 1024, 0.2), (400, 65, 128, 512, 0.0)])
 def test_qkv_dgrad_ffn_chain_backward_equals_its_two_launches(L, frames, S, D, F, pdrop):
     """iq_qkv_dgrad_ffn_chain_bwd (q,k,v data gradient of the layer above + norm2 backward + the feed-forward backward + norm1
     backward + output-projection data gradient: encoder_layer.py:24-33 backwards, one launch) against iq_gemm_bf16_lnbwd for

@@ -96,8 +96,9 @@ __device__ __forceinline__ int fc_kperm(int g) { return ((g & 1) << 1) | (g >> 1
 // its weight's 64-row blocks are further ring "chunks" (two blocks fill one slot exactly), norm2's output tile is their activation
 // fragment, the tail runs between the last FFN chunk and the first of them while they are already in flight.
 // MODE 0: the feed-forward sub-layer alone; 1: PRE; 2: PRE and POST.
-template <int D, int NW, bool DROP1, int MODE>
+template <int D, int NW, int RG, bool DROP1, int MODE>
 __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChainParams p) {
+  constexpr int RW = 16 * RG;                           // rows per wave: RG 16-row groups (2; 1 where 32-row waves would leave CUs idle)
   constexpr bool PRE = MODE >= 1, POST = MODE == 2;
   constexpr int XCPR = D / 8;                           // 16-byte chunks per W1 image row
   constexpr int KS1 = D / 32;                           // k-steps of the first product: 6 | 4
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
   constexpr int W1_BYTES = FC_CHUNK * D * 2, W2_BYTES = D * FC_CHUNK * 2, SLOT = W1_BYTES + W2_BYTES;
   constexpr int W1_PIECES = W1_BYTES / 1024, PIECES = SLOT / 1024;     // 1 KiB DMA pieces per chunk: 48 | 32
   constexpr int PPW = (PIECES + NW - 1) / NW;                          // per wave (a wave past the end repeats the last piece)
-  static_assert(PPW + 10 < 64, "counted vmcnt");
+  static_assert(PPW + 8 * RG < 64, "counted vmcnt");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
   const bool odd = (g & 1) != 0;
   const int F = p.F;
   const int nchunk = F / FC_CHUNK;
-  const long row0 = ((long)blockIdx.x * nwave + wave) * 32;      // this wave's first row
+  const long row0 = ((long)blockIdx.x * nwave + wave) * RW;      // this wave's first row
   const bool have = row0 < p.M;                                   // wave-uniform (a trailing wave may own no rows: it still feeds the ring)
 
   // ---- weight ring: this wave's PPW pieces of every chunk; per-lane source offsets are chunk-invariant ------------------------
@@ -190,11 +191,11 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
 
   // ---- this wave's X1 rows as activation fragments: xf[rg][ks] = row 16 rg + c16, columns 32 ks + 8 kperm(g) .. +7 ----------
   // (PRE: the attention output's rows first -- the projection's activation fragments -- then norm1's output in the same registers)
-  bf16x8 xf[2][KS1];
+  bf16x8 xf[RG][KS1];
   {
     const bf16* src = PRE ? p.A0 : p.X1;
 #pragma unroll
-    for (int rg = 0; rg < 2; ++rg) {
+    for (int rg = 0; rg < RG; ++rg) {
       const long r = min(row0 + rg * 16 + c16, (long)p.M - 1);
 #pragma unroll
       for (int ks = 0; ks < KS1; ++ks)
@@ -203,10 +204,10 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
   }
   // PRE: the residual rows too, in the projection's output layout (pair jp: columns 32 jp + 8 kperm(g) .. +7, as xf) -- fetched per
   // column pair inside the projection loop, each 200-cycle MFMA group waited for an HBM round trip (23 us for the stage)
-  bf16x8 res0[PRE ? 2 : 1][PRE ? KS1 : 1];
+  bf16x8 res0[PRE ? RG : 1][PRE ? KS1 : 1];
   if (PRE) {
 #pragma unroll
-    for (int rg = 0; rg < 2; ++rg) {
+    for (int rg = 0; rg < RG; ++rg) {
       const long r = min(row0 + rg * 16 + c16, (long)p.M - 1);
 #pragma unroll
       for (int jp = 0; jp < KS1; ++jp)
@@ -233,12 +234,12 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
   // see across the loop's back edge and would otherwise wait vmcnt(0) before their first use in EVERY iteration.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-  for (int rg = 0; rg < 2; ++rg)
+  for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) asm volatile("" : "+v"(xf[rg][ks]));
   if (PRE) {
 #pragma unroll
-    for (int rg = 0; rg < 2; ++rg)
+    for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
       for (int jp = 0; jp < KS1; ++jp) asm volatile("" : "+v"(res0[rg][jp]));
   }
@@ -260,15 +261,15 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
     __syncthreads();                                    // every wave's pieces of W0 are in LDS
     if (have) {
       const IqRng rng0 = p.drop0_on ? rng_resolve(p.rng0) : p.rng0;
-      bf16x8 zb[2][KS1];                                // z0 = dropout0(A0 W0^T + b0) + R0, bf16 as stored, [rg][32-column pair]
+      bf16x8 zb[RG][KS1];                                // z0 = dropout0(A0 W0^T + b0) + R0, bf16 as stored, [rg][32-column pair]
 #pragma unroll
       for (int b = 0; b < NB0; ++b) {
 #pragma unroll
         for (int jp = 0; jp < 2; ++jp) {
           const int col = 32 * (2 * b + jp) + (odd ? 16 + 4 * (g - 1) : 4 * g);
-          f32x4 acc1[2][2];
+          f32x4 acc1[RG][2];
 #pragma unroll
-          for (int rg = 0; rg < 2; ++rg) { acc1[rg][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+          for (int rg = 0; rg < RG; ++rg) { acc1[rg][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
           bf16x8 wp[2][2];
           const uint32_t blk = lds0 + SLOT + b * W1_BYTES;
           auto read_w0 = [&](int ks, bf16x8 (&dst)[2]) {
@@ -283,14 +284,15 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
             else FC_LGKM_WAIT(0);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-              acc1[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[0][ks], acc1[0][t], 0, 0, 0);
-              acc1[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[1][ks], acc1[1][t], 0, 0, 0);
+#pragma unroll
+              for (int rg = 0; rg < RG; ++rg)
+                acc1[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[rg][ks], acc1[rg][t], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
           }
           const f32x4 b_lo = *reinterpret_cast<const f32x4*>(vecs + 3 * D + col), b_hi = *reinterpret_cast<const f32x4*>(vecs + 3 * D + col + 4);
 #pragma unroll
-          for (int rg = 0; rg < 2; ++rg) {
+          for (int rg = 0; rg < RG; ++rg) {
             float w[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
       // norm1 on the wave's own rows (two-pass on the bf16-rounded z0, as the tail below); its output is the FFN's fragment
       const float invD0 = 1.0f / (float)D;
 #pragma unroll
-      for (int rg = 0; rg < 2; ++rg) {
+      for (int rg = 0; rg < RG; ++rg) {
         const long grow = row0 + rg * 16 + c16;
         float s1 = 0.f;
 #pragma unroll
@@ -355,19 +357,19 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
     __syncthreads();
     if (ntot > 1) issue_any(1);
 #pragma unroll
-    for (int rg = 0; rg < 2; ++rg)
+    for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
       for (int ks = 0; ks < KS1; ++ks) asm volatile("" : "+v"(xf[rg][ks]));
   }
 
-  f32x4 acc2[2][NT2];
+  f32x4 acc2[RG][NT2];
 #pragma unroll
-  for (int rg = 0; rg < 2; ++rg)
+  for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
     for (int j = 0; j < NT2; ++j) acc2[rg][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // a wave whose 32 rows all exist stores exactly 4 H vectors per chunk: its ring waits can be COUNTED (the stores and the
   // next chunk's pieces stay in flight); a ragged wave waits for everything
-  const bool full = row0 + 32 <= p.M;
+  const bool full = row0 + RW <= p.M;
   const bool gated = p.gate != nullptr;                 // (kernel-uniform) one more store per chunk
   // (Dropout of the hidden activation: four Philox calls per lane and chunk, ~1,800 cycles of integer multiplies, 13-18 of the
   //  kernel's ~62 us.  Computing them one chunk ahead -- all four before the second product, or one call after each of four
@@ -382,10 +384,10 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
 #endif
     if (c == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (b1 image written; the ring's first chunks: above)
     else if (!full || nchunk < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (gated && c + 1 < ntot) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW + 10) : "memory");
-    else if (gated) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if (c + 1 < ntot) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW + 8) : "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (gated && c + 1 < ntot) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW + 4 * RG + 2) : "memory");
+    else if (gated) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * RG + 2) : "memory");
+    else if (c + 1 < ntot) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW + 4 * RG) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * RG) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (c + 2 < ntot) issue_any(c + 2);
@@ -398,14 +400,14 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
     //      read-ahead instead of 32 + 32 (the wide form left no room for the Philox temporaries between the MFMA groups).  The
     //      packed values are the second product's activation fragments. -------------------------------------------------------
     const uint32_t slot_addr = lds0 + (c % FC_NS) * SLOT;
-    bf16x8 hf[2][2];                                    // [rg][k-step of the chunk]
+    bf16x8 hf[RG][2];                                    // [rg][k-step of the chunk]
     uint32_t gbits = 0;                                 // "hidden unit > 0" (= ReLU and dropout gate of the backward), byte 2 jp + rg
     bf16x8 wp[2][2];
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
-      f32x4 acc1[2][2];
+      f32x4 acc1[RG][2];
 #pragma unroll
-      for (int rg = 0; rg < 2; ++rg) { acc1[rg][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int rg = 0; rg < RG; ++rg) { acc1[rg][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       auto read_w1 = [&](int ks, bf16x8 (&dst)[2]) {
         const uint32_t a0 = slot_addr + w1at(ks);
         if (jp == 0) { lds_read128<0 * 16 * D * 2>(dst[0], a0); lds_read128<1 * 16 * D * 2>(dst[1], a0); }
@@ -421,8 +423,9 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
 #ifdef FC_NO_MFMA      // ablation build (timing only)
           asm volatile("" :: "v"(wp[ks & 1][t]));
 #else
-          acc1[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[0][ks], acc1[0][t], 0, 0, 0);
-          acc1[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[1][ks], acc1[1][t], 0, 0, 0);
+#pragma unroll
+          for (int rg = 0; rg < RG; ++rg)
+            acc1[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[rg][ks], acc1[rg][t], 0, 0, 0);
 #endif
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
       const int col = f0 + 32 * jp + (odd ? 16 + 4 * (g - 1) : 4 * g);       // first of this lane's 8 hidden units
       const f32x4 b_lo = *reinterpret_cast<const f32x4*>(b1s + col), b_hi = *reinterpret_cast<const f32x4*>(b1s + col + 4);
 #pragma unroll
-      for (int rg = 0; rg < 2; ++rg) {
+      for (int rg = 0; rg < RG; ++rg) {
         float w[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
     // one dword per lane and chunk: 256 contiguous bytes per wave (a fifth store per chunk when the caller asks for the bits:
     // the counted waits above)
     {
-      if (gated) p.gate[((row0 >> 5) * nchunk + c) * 64 + lane] = gbits;
+      if (gated) p.gate[((row0 / RW) * nchunk + c) * 64 + lane] = gbits;
     }
     // (same read-ahead: groups of four output tiles; group q = k-step q / NG4, tiles 4 (q % NG4) .. + 3)
     constexpr int NG4 = NT2 / 4, NGRP = 2 * NG4;        // 3 | 2 groups per k-step, 6 | 4 per chunk
@@ -479,10 +482,11 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
 #ifdef FC_NO_MFMA
-          asm volatile("" :: "v"(wq[q & 1][t]), "v"(hf[0][jp]), "v"(hf[1][jp]));
+          asm volatile("" :: "v"(wq[q & 1][t]), "v"(hf[0][jp]), "v"(hf[RG - 1][jp]));
 #else
-          acc2[0][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 1][t], hf[0][jp], acc2[0][j0 + t], 0, 0, 0);
-          acc2[1][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 1][t], hf[1][jp], acc2[1][j0 + t], 0, 0, 0);
+#pragma unroll
+          for (int rg = 0; rg < RG; ++rg)
+            acc2[rg][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 1][t], hf[rg][jp], acc2[rg][j0 + t], 0, 0, 0);
 #endif
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
   const float invD = 1.0f / (float)D;
   if (have) {
 #pragma unroll
-  for (int rg = 0; rg < 2; ++rg) {
+  for (int rg = 0; rg < RG; ++rg) {
     const long grow = row0 + rg * 16 + c16;
     float z[NP2][8];
     float s1 = 0.f;
@@ -568,8 +572,8 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
     // q = 0 drains the tail's stores with the ring (chunks q = 0 and 1 have landed then); later: younger than chunk c's pieces are
     // the 8 + 8 Yq stores of the last two iterations and the pieces of chunk c + 1
     if (q == 0 || !full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (c + 1 < ntot) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW + 16) : "memory");
-    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (c + 1 < ntot) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW + 8 * RG) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * RG) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (c + 2 < ntot) issue_any(c + 2);
@@ -580,9 +584,9 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
       if (2 * q + bl >= NBQ) break;                     // (the last chunk of an odd block count is half empty)
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
-        f32x4 acc1[2][2];
+        f32x4 acc1[RG][2];
 #pragma unroll
-        for (int rg = 0; rg < 2; ++rg) { acc1[rg][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int rg = 0; rg < RG; ++rg) { acc1[rg][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         bf16x8 wp[2][2];
         const uint32_t blk = slot_addr + bl * W1_BYTES;
         auto read_wq = [&](int ks, bf16x8 (&dst)[2]) {
@@ -597,15 +601,16 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_fwd_kernel(const FfnChai
           else FC_LGKM_WAIT(0);
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            acc1[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[0][ks], acc1[0][t], 0, 0, 0);
-            acc1[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[1][ks], acc1[1][t], 0, 0, 0);
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg)
+              acc1[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[rg][ks], acc1[rg][t], 0, 0, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
         const int col = FC_CHUNK * (2 * q + bl) + 32 * jp + (odd ? 16 + 4 * (g - 1) : 4 * g);
         const f32x4 b_lo = *reinterpret_cast<const f32x4*>(vecs + 6 * D + col), b_hi = *reinterpret_cast<const f32x4*>(vecs + 6 * D + col + 4);
 #pragma unroll
-        for (int rg = 0; rg < 2; ++rg) {
+        for (int rg = 0; rg < RG; ++rg) {
           float w[8];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -661,8 +666,9 @@ struct FfnChainBwdParams {
 // in 128-column chunk pairs through the same ring, the A0 rows fetched as fragments one pair ahead (inline-asm loads behind
 // counted waits) -- followed by the same LayerNorm-backward tail; its dY rows are this kernel's dO fragments (they never leave
 // the CU on their way into the feed-forward backward), dZ0 / dY0 / partial0 are written for the weight gradients and the tail.
-template <int D, int NW, bool DROP, int MODE>
+template <int D, int NW, int RG, bool DROP, int MODE>
 __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChainBwdParams p) {
+  constexpr int RW = 16 * RG;                           // rows per wave
   constexpr bool POSTB = MODE >= 1, PREB = MODE == 2;
   constexpr int XCPR = D / 8;
   constexpr int KS1 = D / 32;
@@ -677,9 +683,9 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
   const bool odd = (g & 1) != 0;
   const int F = p.F;
   const int nchunk = F / FC_CHUNK;
-  const long row0 = ((long)blockIdx.x * NW + wave) * 32;
+  const long row0 = ((long)blockIdx.x * NW + wave) * RW;
   const bool have = row0 < p.M;
-  const bool full = row0 + 32 <= p.M;
+  const bool full = row0 + RW <= p.M;
 
   // ---- weight ring (as in the forward kernel: "W1" = W2t rows f0 .. f0+63 x D, "W2" = W1t rows 0 .. D-1 x hidden f0 .. f0+63) -----
   // (per-lane source offsets recomputed per chunk: seven resident registers more made the D = 192 build spill)
@@ -706,9 +712,9 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
       __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(base + off), (lds_void_t*)(slot + pc * 1024), 16, 0, 0);
     }
   };
-  long rowc[2];
+  long rowc[RG];
 #pragma unroll
-  for (int rg = 0; rg < 2; ++rg) rowc[rg] = min(row0 + rg * 16 + c16, (long)p.M - 1);
+  for (int rg = 0; rg < RG; ++rg) rowc[rg] = min(row0 + rg * 16 + c16, (long)p.M - 1);
   // slot-relative byte offsets of this lane's fragment reads (as in the forward kernel)
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
   // (384-byte rows: the swizzle leaves the chunk's bits above 3 alone, k-step ks reads 128 (ks >> 1) bytes behind k-step ks & 1:
@@ -721,15 +727,15 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
 #pragma unroll
   for (int jp = 0; jp < 2; ++jp) w2off[jp] = (uint32_t)(W1_BYTES + c16 * 128 + fc_swz<8>(c16, 4 * jp + g) * 16);
 
-  bf16x8 xf[2][KS1];
-  f32x4 acc2[2][NT2];
+  bf16x8 xf[RG][KS1];
+  f32x4 acc2[RG][NT2];
 #pragma unroll
-  for (int rg = 0; rg < 2; ++rg)
+  for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
     for (int j = 0; j < NT2; ++j) acc2[rg][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // ---- acc2 += h (two 32-unit k-steps of this wave's rows, as fragments) x the W2-type image at img2 + W1_BYTES: model columns
   //      16 j .. +15, units 0 .. 63 (read-ahead in groups of four output tiles; group q = k-step q / NG4, tiles 4 (q % NG4) .. + 3)
-  auto second_product = [&](uint32_t img2, bf16x8 (&h)[2][2]) {
+  auto second_product = [&](uint32_t img2, bf16x8 (&h)[RG][2]) {
     constexpr int NG4 = NT2 / 4, NGRP = 2 * NG4;
     bf16x8 wq[2][4];
     auto read_w2 = [&](auto qc, bf16x8 (&dst)[4]) {
@@ -749,8 +755,9 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
         constexpr int jp = q / NG4, j0 = 4 * (q % NG4);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          acc2[0][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 1][t], h[0][jp], acc2[0][j0 + t], 0, 0, 0);
-          acc2[1][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 1][t], h[1][jp], acc2[1][j0 + t], 0, 0, 0);
+#pragma unroll
+          for (int rg = 0; rg < RG; ++rg)
+            acc2[rg][j0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 1][t], h[rg][jp], acc2[rg][j0 + t], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         self(self, std::integral_constant<int, q + 1>{});
@@ -766,13 +773,13 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
   //      dX -- spilled ~80 registers at D = 192, and the allocator then also spilled loop-invariant fragments).
   //      reload: dY goes back into the image and is re-read as the activation fragments xf of the product that follows.
   constexpr int LDI = D;                                // image row (elements; unpadded: exactly four images per ring slot)
-  constexpr int IMG = 32 * LDI * 2;                     // bytes per wave: 12,288 | 8,192
-  static_assert(SLOT % IMG == 0 && FC_MAXW <= 2 * (SLOT / IMG), "whole wave images, seven of them in two ring slots");
+  constexpr int IMG = RW * LDI * 2;                     // bytes per wave: 12,288 | 8,192 (RG = 2)
+  static_assert(SLOT % IMG == 0 && NW <= 2 * (SLOT / IMG), "whole wave images, all of them in two ring slots");
   auto ln_tail = [&](const bf16* Rp, const bf16* Zp, const float* meanp, const float* rstdp, const float* gammap, const IqRng& rngx,
                      uint32_t thr, float dsc, bf16* dZp, bf16* dYp, bf16* img, float* wsp, auto reload_c) {
     constexpr bool reload = decltype(reload_c)::value;
 #pragma unroll
-    for (int rg = 0; rg < 2; ++rg) {
+    for (int rg = 0; rg < RG; ++rg) {
       const long gr = min(row0 + rg * 16 + c16, (long)p.M - 1);
   #pragma unroll
       for (int jp = 0; jp < NP2; ++jp) {
@@ -806,7 +813,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
         for (int e = 0; e < 8; ++e) { ag[v][e] = 0.f; ab[v][e] = 0.f; }
       }
   #pragma unroll
-      for (int it = 0; it < 4; ++it) {
+      for (int it = 0; it < RW / 8; ++it) {
         const int rl = it * 8 + rsub;
         const long row = row0 + rl;
         const bool ok = row < p.M;
@@ -857,7 +864,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
       if (reload) {                                       // dY rows as activation fragments (the dO fragments are dead)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   #pragma unroll
-        for (int rg = 0; rg < 2; ++rg)
+        for (int rg = 0; rg < RG; ++rg)
   #pragma unroll
           for (int ks = 0; ks < KS1; ++ks)
             xf[rg][ks] = *reinterpret_cast<const bf16x8*>(img + (rg * 16 + c16) * LDI + 32 * ks + 8 * fc_kperm(g));
@@ -897,7 +904,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
   // the loop would make it drain the ring), issued one chunk ahead, retired by the loop's own counted wait.
   // (address = a wave-uniform base in scalar registers + a 32-bit lane offset, here and for the gH stores below: 64-bit per-lane
   //  pointers live across the chunk loop were what the register allocator spilled -- and reloaded inside the loop)
-  const uint32_t* gate_wave = p.gate + (row0 >> 5) * nchunk * 64;
+  const uint32_t* gate_wave = p.gate + (row0 / RW) * nchunk * 64;
   const uint32_t lane4 = (uint32_t)lane * 4u;
   uint32_t gnext;
   auto load_gate = [&](int c) {
@@ -928,13 +935,13 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
       }
     };
     // this wave's A0 rows of pair i as fragments [half][rg][k-step]: inline-asm loads (see load_gate), one pair ahead
-    bf16x8 aF[2][2][2][2];
+    bf16x8 aF[2][2][RG][2];
     auto load_a = [&](int i) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         if (2 * i + h >= NC0) break;
 #pragma unroll
-        for (int rg = 0; rg < 2; ++rg)
+        for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
           for (int jp = 0; jp < 2; ++jp) {
             const bf16* src = p.A0 + rowc[rg] * K0 + (2 * i + h) * FC_CHUNK + 32 * jp + 8 * fc_kperm(g);
@@ -961,7 +968,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
       for (int h = 0; h < 2; ++h) {
         if (2 * i + h >= NC0) break;
 #pragma unroll
-        for (int rg = 0; rg < 2; ++rg)
+        for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
           for (int jp = 0; jp < 2; ++jp) asm volatile("" : "+v"(aF[i & 1][h][rg][jp]));       // (landed: the wait above)
         second_product(slot_addr + h * W1_BYTES - W1_BYTES, aF[i & 1][h]);
@@ -979,7 +986,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
     if (nchunk > 1) issue_chunk(1);                      // (the images are dead)
     reduce_partial(p.partial0);
 #pragma unroll
-    for (int rg = 0; rg < 2; ++rg)
+    for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
       for (int j = 0; j < NT2; ++j) acc2[rg][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   } else {
@@ -987,7 +994,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
     if (nchunk > 1) issue_chunk(1);
     // ---- this wave's dO rows as activation fragments; the gate rows of chunk 0 --------------------------------------------------
 #pragma unroll
-    for (int rg = 0; rg < 2; ++rg)
+    for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
       for (int ks = 0; ks < KS1; ++ks)
         xf[rg][ks] = have ? *reinterpret_cast<const bf16x8*>(p.dO + rowc[rg] * D + 32 * ks + 8 * fc_kperm(g)) : bf16x8{};
@@ -995,7 +1002,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 #pragma unroll
-  for (int rg = 0; rg < 2; ++rg) {
+  for (int rg = 0; rg < RG; ++rg) {
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) asm volatile("" : "+v"(xf[rg][ks]));
   }
@@ -1006,7 +1013,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
     // pieces of chunk c+1 | ...: "at most 4 outstanding" = gate(c) and ring chunk c+1 (hence c) have landed.  A ragged wave's
     // stores are predicated (their count is not known): it waits for everything.
     if (c > 0) {
-      if (full) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (full) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * RG) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
@@ -1019,13 +1026,13 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
     // ---- first product + gate, 32 hidden units (two column tiles) at a time -- 16 accumulator registers instead of 32: with the
     //      gate rows (16) beside the 144 of the dO fragments and the second product's accumulators, the wide form spilled ------
     const uint32_t slot_addr = lds0 + (c % FC_NS) * SLOT;
-    bf16x8 hf[2][2];
+    bf16x8 hf[RG][2];
     bf16x8 wp[2][2];
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
-      f32x4 acc1[2][2];
+      f32x4 acc1[RG][2];
 #pragma unroll
-      for (int rg = 0; rg < 2; ++rg) { acc1[rg][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int rg = 0; rg < RG; ++rg) { acc1[rg][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       auto read_w1 = [&](int ks, bf16x8 (&dst)[2]) {
         const uint32_t a0 = slot_addr + w1at(ks);
         if (jp == 0) { lds_read128<0 * 16 * D * 2>(dst[0], a0); lds_read128<1 * 16 * D * 2>(dst[1], a0); }
@@ -1038,14 +1045,15 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
         else FC_LGKM_WAIT(0);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          acc1[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[0][ks], acc1[0][t], 0, 0, 0);
-          acc1[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[1][ks], acc1[1][t], 0, 0, 0);
+#pragma unroll
+          for (int rg = 0; rg < RG; ++rg)
+            acc1[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[rg][ks], acc1[rg][t], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
       // gate: ReLU and dropout of the FORWARD hidden unit are both "Hid > 0"; the packed tile feeds the second product
 #pragma unroll
-      for (int rg = 0; rg < 2; ++rg) {
+      for (int rg = 0; rg < RG; ++rg) {
         float w[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1063,7 +1071,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
     asm volatile("" ::: "memory");
     if (c + 1 < nchunk) load_gate(c + 1);
 #pragma unroll
-    for (int rg = 0; rg < 2; ++rg) {
+    for (int rg = 0; rg < RG; ++rg) {
       const bf16* base = p.gH + (row0 + rg * 16) * F + f0;          // wave-uniform
       if (row0 + rg * 16 + c16 < p.M) {
         asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(gh_lane), "v"(hf[rg][0]), "s"(base) : "memory");
@@ -1111,9 +1119,9 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
     const uint32_t blk = lds0 + (b < 2 ? sC * SLOT + b * W1_BYTES : s2 * SLOT);
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
-      f32x4 acc1[2][2];
+      f32x4 acc1[RG][2];
 #pragma unroll
-      for (int rg = 0; rg < 2; ++rg) { acc1[rg][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int rg = 0; rg < RG; ++rg) { acc1[rg][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       bf16x8 wp[2][2];
       auto read_w = [&](int ks, bf16x8 (&dst)[2]) {
         const uint32_t a0 = blk + w1at(ks);
@@ -1127,14 +1135,15 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
         else FC_LGKM_WAIT(0);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          acc1[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[0][ks], acc1[0][t], 0, 0, 0);
-          acc1[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[1][ks], acc1[1][t], 0, 0, 0);
+#pragma unroll
+          for (int rg = 0; rg < RG; ++rg)
+            acc1[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[ks & 1][t], xf[rg][ks], acc1[rg][t], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
       const int col = FC_CHUNK * b + 32 * jp + (odd ? 16 + 4 * (g - 1) : 4 * g);
 #pragma unroll
-      for (int rg = 0; rg < 2; ++rg) {
+      for (int rg = 0; rg < RG; ++rg) {
         float w[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1150,22 +1159,30 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
   }
 }
 
-// waves per workgroup: 32 rows each; one workgroup per CU (the ring is most of a CU's LDS).  Seven waves cover cfg B's 50,432 rows
-// with 226 workgroups; fewer rows simply leave CUs or waves idle (the training plan takes these kernels only above 32,768 rows:
-// builds with 2 and 4 waves per workgroup existed for smaller M, were never faster than the tiled GEMMs there, and -- 24 DMA
-// pieces per wave instead of 7 -- spilled up to 176 scalar and 75 vector registers)
-inline int chain_waves(int M) { (void)M; return FC_MAXW; }
+// Rows per wave and waves per workgroup (one workgroup per CU: the ring is most of a CU's LDS).  32-row waves, seven per
+// workgroup, cover cfg B's 50,432 rows with 226 workgroups.  Up to 32,768 rows (cfg C at 256 frames: 16,640) that shape would
+// leave most CUs idle: 16-row waves, five per workgroup up to 20,480 rows (cfg C: 208 workgroups), eight above.  (Builds with 2
+// and 4 waves of 32 rows existed for small M: never faster than the tiled GEMMs there, and -- 24 DMA pieces per wave instead of
+// 7 -- they spilled up to 176 scalar and 75 vector registers.)
+struct ChainShape { int rg, nw; };
+inline ChainShape chain_shape(int M) {
+  if (M <= 20480) return ChainShape{1, 5};
+  if (M <= 32768) return ChainShape{1, 8};
+  return ChainShape{2, FC_MAXW};
+}
+inline int chain_waves(int M) { return chain_shape(M).nw; }
+inline long chain_units(int M) { const int rw = 16 * chain_shape(M).rg; return ((long)M + rw - 1) / rw; }
 
-template <int D, int NW>
+template <int D, int NW, int RG>
 int launch_chain(const FfnChainParams& p, hipStream_t st) {
   constexpr int SLOT = 2 * FC_CHUNK * D * 2;
   const size_t lds = (size_t)FC_NS * SLOT + ((size_t)p.F + 9 * D) * sizeof(float);     // ring (147,456 | 98,304 B) + b1 + nine [D] vectors
-  const long units = ((long)p.M + 31) / 32;
+  const long units = ((long)p.M + 16 * RG - 1) / (16 * RG);
   const int grid = (int)((units + NW - 1) / NW);
 #define FC_LAUNCH(DROP_, MODE_)                                                                                               \
   do {                                                                                                                        \
-    auto k = ffn_chain_fwd_kernel<D, NW, DROP_, MODE_>;                                                                       \
-    static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    auto k = ffn_chain_fwd_kernel<D, NW, RG, DROP_, MODE_>;                                                                   \
+    static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     (void)attr;                                                                                                               \
     k<<<grid, NW * 64, lds, st>>>(p);                                                                                         \
   } while (0)
@@ -1176,18 +1193,22 @@ int launch_chain(const FfnChainParams& p, hipStream_t st) {
   return iq_launch_status();
 }
 template <int D>
-int launch_chain_d(const FfnChainParams& p, hipStream_t st) { return launch_chain<D, FC_MAXW>(p, st); }
+int launch_chain_d(const FfnChainParams& p, hipStream_t st) {
+  const ChainShape sh = chain_shape(p.M);
+  if (sh.rg == 2) return launch_chain<D, FC_MAXW, 2>(p, st);
+  return sh.nw == 5 ? launch_chain<D, 5, 1>(p, st) : launch_chain<D, 8, 1>(p, st);
+}
 
-template <int D, int NW>
+template <int D, int NW, int RG>
 int launch_chain_bwd(const FfnChainBwdParams& p, hipStream_t st) {
   constexpr int SLOT = 2 * FC_CHUNK * D * 2;
   const size_t lds = (size_t)FC_NS * SLOT + (size_t)NW * 2 * D * sizeof(float);     // ring + the waves' gamma / beta column sums
-  const long units = ((long)p.M + 31) / 32;
+  const long units = ((long)p.M + 16 * RG - 1) / (16 * RG);
   const int grid = (int)((units + NW - 1) / NW);
 #define FC_LAUNCHB(DROP_, MODE_)                                                                                              \
   do {                                                                                                                        \
-    auto k = ffn_chain_bwd_kernel<D, NW, DROP_, MODE_>;                                                                       \
-    static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    auto k = ffn_chain_bwd_kernel<D, NW, RG, DROP_, MODE_>;                                                                   \
+    static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     (void)attr;                                                                                                               \
     k<<<grid, NW * 64, lds, st>>>(p);                                                                                         \
   } while (0)
@@ -1198,7 +1219,11 @@ int launch_chain_bwd(const FfnChainBwdParams& p, hipStream_t st) {
   return iq_launch_status();
 }
 template <int D>
-int launch_chain_bwd_d(const FfnChainBwdParams& p, hipStream_t st) { return launch_chain_bwd<D, FC_MAXW>(p, st); }
+int launch_chain_bwd_d(const FfnChainBwdParams& p, hipStream_t st) {
+  const ChainShape sh = chain_shape(p.M);
+  if (sh.rg == 2) return launch_chain_bwd<D, FC_MAXW, 2>(p, st);
+  return sh.nw == 5 ? launch_chain_bwd<D, 5, 1>(p, st) : launch_chain_bwd<D, 8, 1>(p, st);
+}
 
 }  // namespace
 
@@ -1292,12 +1317,12 @@ extern "C" int iq_attn_out_ffn_chain_fwd(const void* A, const void* Wo, const fl
 extern "C" int iq_ffn_chain_bwd_partial_rows(int M) {      // one per workgroup
   if (M <= 0) return 0;
   const int nw = chain_waves(M);
-  return (int)((((long)M + 31) / 32 + nw - 1) / nw);
+  return (int)((chain_units(M) + nw - 1) / nw);
 }
 
-extern "C" size_t iq_ffn_chain_gate_bytes(int M, int F) {
+extern "C" size_t iq_ffn_chain_gate_bytes(int M, int F) {    // one dword per lane, chunk and wave (a wave = 32 or 16 rows)
   if (M <= 0 || F <= 0) return 0;
-  return (size_t)((M + 31) / 32) * (size_t)(F / FC_CHUNK) * 64 * sizeof(uint32_t);
+  return (size_t)chain_units(M) * (size_t)(F / FC_CHUNK) * 64 * sizeof(uint32_t);
 }
 
 namespace {

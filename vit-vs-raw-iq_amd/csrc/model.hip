@@ -245,15 +245,16 @@ WsPlan plan_ws(const iq_model* m, int B) {
 // 33.1 but K 1024 62.3 vs 55.7: its 64-row blocks re-stream the 512 KB weight twice as often).
 inline bool use_fused_ln(int D, int K) { return iq_gemm_ln_supported(D, K) && (D <= 192 || K <= 256); }
 
-// The feed-forward sub-layer of a frame in one workgroup (ffn_chain.hip).  IQ_TUNE_FFN_CHAIN=0|1 forces the choice (probes).
-// Measured (scripts/layer_kernels.py): cfg B (M = 50,432 rows, D 192, F 768) 60.9 us against 38.5 + 35.7 for the two launches;
-// cfg C (M = 16,640, D 128, F 1024) 42.5 against 18.9 + 19.2 -- with 32 rows per wave a small M leaves two or four waves per
-// CU, so the chain runs only where its workgroups are full (7 waves: M > 32,768 rows).
+// The encoder layer from the attention output on as one launch per direction (ffn_chain.hip).  IQ_TUNE_FFN_CHAIN=0|1 forces the
+// choice (probes); IQ_TUNE_FFN_CHAIN_MIN_ROWS moves the threshold.  Measured (same box each, profiles/r03_probes.txt): cfg B
+// (M = 50,432 rows, D 192, F 768, 7 waves of 32 rows per workgroup) 5.72 -> 4.88 ms per step; cfg C (M = 16,640, D 128, F 1024,
+// 5 waves of 16 rows) 1.313 -> 1.191 ms; cfg A (M = 1,280: 16 workgroups) equal -- below 8,192 rows the tiled GEMMs stay.
 inline bool use_ffn_chain(int M, int S, int D, int F) {
   static const int tune = [] { const char* e = getenv("IQ_TUNE_FFN_CHAIN"); return e ? atoi(e) : -1; }();
+  static const int min_rows = [] { const char* e = getenv("IQ_TUNE_FFN_CHAIN_MIN_ROWS"); return e ? atoi(e) : 8192; }();
   if (!iq_ffn_chain_supported(S, D, F) || tune == 0) return false;
   if (tune == 1) return true;
-  return M > 32768;
+  return M >= min_rows;
 }
 
 // ... with the attention output projection + norm1 as its first stage (IQ_TUNE_CHAIN_PRE=0: the projection stays a launch of its own)
