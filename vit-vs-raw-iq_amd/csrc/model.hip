@@ -257,14 +257,16 @@ inline bool use_ffn_chain(int M, int S, int D, int F) {
   return M >= min_rows;
 }
 
-// ... with the attention output projection + norm1 as its first stage (IQ_TUNE_CHAIN_PRE=0: the projection stays a launch of its own)
-// and the next layer's q,k,v projection as its last, the backward launch with the output projection's data gradient behind it
-// (2, default; 1: without).  3: the backward launch also takes the q,k,v data gradient of the layer above + norm2 backward in
-// front (iq_qkv_dgrad_ffn_chain_bwd) -- measured equal, 108.5 us against 68.1 + 39.6 for cfg B, step 4.896 vs 4.876 ms: that stage
-// moves 134 MB for 11 GFLOP and every workgroup runs it at the same time, so it is as HBM-bound inside the launch as outside it.
-inline int use_chain_pre() {
-  static const int tune = [] { const char* e = getenv("IQ_TUNE_CHAIN_PRE"); return e ? atoi(e) : 2; }();
-  return tune;
+// ... with the attention output projection + norm1 as its first stage (IQ_TUNE_CHAIN_PRE=0: the projection stays a launch of its
+// own) and the next layer's q,k,v projection as its last, the backward launch with the output projection's data gradient behind
+// it (2; 1: without).  3: the backward launch also takes the q,k,v data gradient of the layer above + norm2 backward in front
+// (iq_qkv_dgrad_ffn_chain_bwd).  Measured: cfg B 108.5 us against 68.1 + 39.6, step 4.896 vs 4.876 ms -- that stage moves 134 MB
+// for 11 GFLOP and every workgroup runs it at the same time, it is as HBM-bound inside the launch as outside; on the small
+// geometries a launch less is worth 1 % (cfg C 1.190 -> 1.180 ms, reference default ViT 1.629 -> 1.612).  Default: 3 up to
+// 32,768 rows, 2 above.
+inline int use_chain_pre(int M) {
+  static const int tune = [] { const char* e = getenv("IQ_TUNE_CHAIN_PRE"); return e ? atoi(e) : -1; }();
+  return tune >= 0 ? tune : M <= 32768 ? 3 : 2;
 }
 
 #define IQ_TRY(expr, what)                                                              \
@@ -514,8 +516,8 @@ extern "C" int iq_model_forward(iq_model_t* m, const float* src, int batch, void
     const iq_dropout_t dr1 = site(m, seed, step_dev, 1 + 3 * l, tr);
     const iq_dropout_t drh = site(m, seed, step_dev, 2 + 3 * l, tr);
     const iq_dropout_t dr2 = site(m, seed, step_dev, 3 + 3 * l, tr);
-    if (use_ffn_chain(M, S, D, F) && use_chain_pre()) {
-      const bool next = l + 1 < c.n_layers && use_chain_pre() >= 2;
+    if (use_ffn_chain(M, S, D, F) && use_chain_pre(M)) {
+      const bool next = l + 1 < c.n_layers && use_chain_pre(M) >= 2;
       IQ_TRY(iq_attn_out_ffn_chain_fwd(ws + a.att, m->sh(o.wo), P + o.bo, &dr1, x, P + o.g1, P + o.be1, ws + a.z1, ws + a.x1,
                                        (float*)(ws + a.mean1), (float*)(ws + a.rstd1), m->sh(o.w1), P + o.b1, &drh, ws + a.hid,
                                        m->sh(o.w2), P + o.b2, &dr2, P + o.g2, P + o.be2, 1e-12f, ws + a.z2, ws + a.x2,
@@ -654,7 +656,7 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
     const iq_reduce_seg_t lnseg[4] = {{lp2, rows2, 2L * D, G + o.g2, D}, {lp2 + D, rows2, 2L * D, G + o.be2, D},
                                       {lp1, rows1, 2L * D, G + o.g1, D}, {lp1 + D, rows1, 2L * D, G + o.be1, D}};
     const iq_dropout_t dr1 = m->bwd_site(1 + 3 * l, step_dev, tr);
-    const bool post = chain && use_chain_pre() >= 2;       // ... and the output projection's data gradient behind it
+    const bool post = chain && use_chain_pre(M) >= 2;       // ... and the output projection's data gradient behind it
     if (chain && deferred) {
       const LayerOff& ou = m->L[l + 1];
       const iq_dropout_t dr2b = m->bwd_site(3 + 3 * l, step_dev, tr);
@@ -689,7 +691,7 @@ extern "C" int iq_model_backward(iq_model_t* m, const float* dlogits, const floa
     // below, that GEMM overwrites gZ / gY and the norm2 partial rows, which the weight gradients / their reduce still read.
     IQ_TRY(iq_gemm_bf16_wgrad_grouped(wg, 4, M, wws, w.wgrad_ws_bytes, accumulate, 0, lnseg, 4, stream), "layer weight gradients");
     // ... unless the layer below takes it into its own chain launch (iq_qkv_dgrad_ffn_chain_bwd)
-    deferred = l > 0 && fuse2 && chain && post && use_chain_pre() >= 3 && sidx - 1 >= stage_lo;
+    deferred = l > 0 && fuse2 && chain && post && use_chain_pre(M) >= 3 && sidx - 1 >= stage_lo;
     if (deferred) continue;
     if (l > 0 && fuse2) {
       const LayerOff& ob = m->L[l - 1];
