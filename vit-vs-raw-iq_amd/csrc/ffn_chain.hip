@@ -1289,7 +1289,7 @@ int chain_fwd(const ChainPre* pre, const void* X1, const void* W1, const float* 
   if (pre) { more_bytes += 2.0 * (M * D * 3 + (double)D * D) + 8.0 * M; more_flops += 2.0 * M * D * D; }
   if (p.Wq) { more_bytes += 2.0 * (M * 3 * D + 3.0 * D * D); more_flops += 6.0 * M * D * D; }
   IQ_PROF_K(2.0 * (M * D * 3 + M * F + 2.0 * D * F) + 8.0 * M + more_bytes, 4.0 * M * D * F + more_flops,
-            "ffn_chain_fwd_kernel<%d, %d, %s, %d>", D, chain_waves(p.M), p.drop1_on ? "true" : "false", p.Wq ? 2 : pre ? 1 : 0);
+            "ffn_chain_fwd_kernel<%d, %d, %d, %s, %d>", D, chain_waves(p.M), chain_shape(p.M).rg, p.drop1_on ? "true" : "false", p.Wq ? 2 : pre ? 1 : 0);
   return D == 192 ? launch_chain_d<192>(p, st) : launch_chain_d<128>(p, st);
 }
 }  // namespace
@@ -1377,7 +1377,7 @@ int chain_bwd(const ChainBwdPre* pre, const void* dO, const void* W2t, const voi
     bytes += 2.0 * (M * 3 * D + M * D * (3 + (p.drop_on ? 1 : 0) - 1) + 3.0 * D * D) + 8.0 * M;
     flops += 6.0 * M * D * D;
   }
-  IQ_PROF_K(bytes, flops, "ffn_chain_bwd_kernel<%d, %d, %s, %d>", D, chain_waves(p.M), p.drop_on ? "true" : "false", pre ? 2 : Wot ? 1 : 0);
+  IQ_PROF_K(bytes, flops, "ffn_chain_bwd_kernel<%d, %d, %d, %s, %d>", D, chain_waves(p.M), chain_shape(p.M).rg, p.drop_on ? "true" : "false", pre ? 2 : Wot ? 1 : 0);
   return D == 192 ? launch_chain_bwd_d<192>(p, st) : launch_chain_bwd_d<128>(p, st);
 }
 }  // namespace
