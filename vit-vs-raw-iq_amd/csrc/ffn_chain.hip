@@ -1,17 +1,21 @@
-// The position-wise feed-forward sub-layer + norm2 in ONE launch, the hidden activation never re-read (gfx950):
+// The encoder layer from the attention output on as ONE launch per direction (gfx950).  Core: the position-wise feed-forward
+// sub-layer + norm2, the hidden activation never re-read:
 //
-//     H[M,F]  = dropout1(relu(X1[M,D] * W1[F,D]^T + b1))                      bf16, written once (backward reads it)
+//     H[M,F]  = dropout1(relu(X1[M,D] * W1[F,D]^T + b1))                      bf16, written once (the weight gradients read it)
 //     Z[M,D]  = dropout2(H * W2[D,F]^T + b2) + X1                              bf16 (kept for backward)
 //     X[M,D]  = gamma * (Z - mean) * rstd + beta ; mean, rstd fp32 [M]         (norm2, eps inside the square root)
 //
 // = PositionwiseFeedForward.forward (V/models/layers/position_wise_feed_forward.py:12-17: Linear, ReLU, Dropout, Linear)
-// followed by `x = norm2(dropout2(ffn(x)) + x)` of EncoderLayer.forward (V/models/blocks/encoder_layer.py:30-33).
+// followed by `x = norm2(dropout2(ffn(x)) + x)` of EncoderLayer.forward (V/models/blocks/encoder_layer.py:30-33); optional stages
+// in front (attention output projection + dropout + residual + norm1, encoder_layer.py:24-28) and behind (the NEXT layer's packed
+// q,k,v projection, multi_head_attention.py:17-19); the backward kernel mirrors it (see there).
 //
 // Run as two launches (FFN1 GEMM, then FFN2 GEMM + LayerNorm) the hidden activation H -- 4x the width of every other
 // activation -- is written to HBM and read straight back (cfg B: 77.5 MB each way per layer), and each launch pays its own
 // pipeline fill and drain.  Here the ROWS are stationary and the WEIGHTS stream:
-//   * a wave owns 32 consecutive rows (two 16-row groups) for the whole kernel.  Its X1 rows sit in registers as MFMA
-//     fragments (loaded once, fragment-shaped, straight from global memory), its Z accumulators (32 rows x D, fp32) too;
+//   * a wave owns 32 consecutive rows (two 16-row groups; 16 rows where that leaves CUs idle: chain_shape) for the whole kernel.
+//     Its X1 rows sit in registers as MFMA fragments (loaded once, fragment-shaped, straight from global memory), its Z
+//     accumulators (32 rows x D, fp32) too;
 //   * the hidden dimension is walked in chunks of 64 units.  Per chunk: acc1 = X1 W1_c^T (K = D), epilogue (bias, ReLU,
 //     Philox dropout, round to bf16, 16-byte store of H) -- and the eight bf16 values a lane has just packed ARE its
 //     activation fragment of the second product (an accumulator tile as the next MFMA's operand: the k-slot order inside an
@@ -25,11 +29,14 @@
 //   * tail: z = dropout2(acc2 + b2) + x1 with x1 taken from the X1 fragments (the same column permutation makes them exactly
 //     the 8 columns a lane owns after the tail's permlane swap), LayerNorm statistics two-pass on the bf16-rounded z by lane
 //     sums + two shuffles (a wave owns whole rows), Z / X / statistics stored from registers.
-// K order of both products is the plain ascending one (chunks, then 32-unit steps): H and Z are bit-identical to
-// iq_gemm_bf16_nt + iq_gemm_bf16_ln.  First version of this file (round 3, measured, replaced; kept as
-// scripts/dbg/variants/ffn_chain_v1_frame_images.hip): one workgroup per frame with X1 and H_c as LDS images and weight
-// fragments loaded from L2 into registers 1-2 k-steps ahead: 79 us for cfg B's layer against 38 + 37 for the two launches --
-// every k-step exposed an L2 round trip, and registers left no room to look further ahead.  A ring in LDS costs no registers.
+// The chunks run in ascending order, but inside a 32-unit MFMA step the k-slots are permuted: H and Z equal iq_gemm_bf16_nt +
+// iq_gemm_bf16_ln up to fp32 summation order inside one MFMA, i.e. at bf16 rounding ties (tests/test_gpu_kernels.py bounds the
+// fraction).  Measured, cfg B layer: 89.6 us for the whole forward launch against 126 for the four it replaces; it is bound by
+// the vector ALU (per chunk and wave 601 instructions, half of them Philox, against 96 MFMAs), DESIGN.md section 6.
+// First version of this file (round 3, measured, replaced; kept as scripts/dbg/variants/ffn_chain_v1_frame_images.hip): one
+// workgroup per frame with X1 and H_c as LDS images and weight fragments loaded from L2 into registers 1-2 k-steps ahead: 79 us
+// for cfg B's FFN against 38 + 37 for the two launches -- every k-step exposed an L2 round trip, and registers left no room
+// to look further ahead.  A ring in LDS costs no registers.
 #include <stdlib.h>
 
 #include <type_traits>
