@@ -875,7 +875,9 @@ def attn_ref(qkv, Bf, S, H, dh):
                                        # whole 32-row tiles, the largest S they take
                                        (40, 12, 16, 2), (96, 4, 32, 3), (128, 8, 16, 2), (64, 3, 64, 5),
                                        # backward keeps the staged side in LDS in chunks (conv1d embedding, S = 1025)
-                                       (1025, 8, 32, 1), (1025, 4, 64, 1), (481, 2, 64, 1), (700, 2, 32, 2)])
+                                       (1025, 8, 32, 1), (1025, 4, 64, 1), (481, 2, 64, 1), (700, 2, 32, 2),
+                                       # the benchmarked batch: more (frame, head) workgroups than the chip holds at once
+                                       (197, 3, 64, 256), (145, 4, 32, 150)])
 def test_attention_fwd_bwd(L, S, H, dh, Bf):
     N = _N()
     assert L.iq_attn_supported(S, dh) == 1
