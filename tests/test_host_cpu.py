@@ -100,6 +100,15 @@ def test_host_only_queries_work_without_a_gpu():
     bad = N.ModelCfg(kind=0, in_channels=1, img_h=32, img_w=32, patch=16, seq_length=0, conv_k=0, use_cls=1,
                      num_classes=3, d_model=100, n_head=4, n_layers=1, ffn_hidden=64, drop_prob=0.0)
     assert L.iq_model_create(ctypes.byref(bad), ctypes.byref(h)) != 0      # head dim 25: refused, not emulated
+    # the one-launch layer tail (ffn_chain.hip): widths 128 | 192, hidden size in 64-unit chunks, ring + vectors within 160 KB
+    assert L.iq_ffn_chain_supported(197, 192, 768) == 1 and L.iq_ffn_chain_supported(65, 128, 1024) == 1
+    assert L.iq_ffn_chain_supported(197, 256, 1024) == 0 and L.iq_ffn_chain_supported(197, 192, 96) == 0
+    assert L.iq_ffn_chain_supported(197, 192, 4096) == 0
+    # rows per wave / waves per workgroup by row count: 32 x 7 above 32,768 rows, 16 x 8 down to 20,481, 16 x 5 below
+    for M, rw, nw in ((50432, 32, 7), (33024, 32, 7), (32768, 16, 8), (25216, 16, 8), (20480, 16, 5), (16640, 16, 5), (153, 16, 5)):
+        units = (M + rw - 1) // rw
+        assert L.iq_ffn_chain_bwd_partial_rows(M) == (units + nw - 1) // nw, M
+        assert L.iq_ffn_chain_gate_bytes(M, 768) == units * 12 * 256, M
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -199,3 +208,90 @@ def test_pingpong_kernels_hold_their_state_in_registers():
                 seen += 1
                 assert scratch == 0 and spill == 0 and vgpr <= 256, (name, scratch, vgpr, spill)
     assert seen == 3 + 3 + 1
+
+
+def test_chain_kernels_keep_scratch_out_of_their_chunk_loops():
+    """The one-launch layer kernels (ffn_chain.hip) stream their weights through an LDS ring behind COUNTED `s_waitcnt vmcnt(N)`:
+    a register reloaded from scratch inside a chunk loop is a vector-memory load the counts do not know, and the compiler waits
+    `vmcnt(0)` for it -- the ring drains every iteration (it happened twice while these kernels were written; spills OUTSIDE
+    the loops, in the one-off tails, are harmless).  Checked in the gfx950 ISA: no scratch access in any loop that issues MFMAs."""
+    import re
+    import tempfile
+    csrc = os.path.join(ROOT, "vit-vs-raw-iq_amd", "csrc")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + csrc, "-I" + os.path.join(ROOT, "include"),
+                           "-S", "--cuda-device-only", os.path.join(csrc, "ffn_chain.hip"), "-o", out], stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    os.unlink(out)
+    kernels = loops = 0
+    for fn in re.split(r"\n(?=_ZN\S*ffn_chain_(?:fwd|bwd)_kernel\S*:)", text)[1:]:
+        name = fn.split(":", 1)[0]
+        lines = re.split(r"\n\.Lfunc_end\d+:", fn, 1)[0].split("\n")      # (a kernel may hold several s_endpgm)
+        # basic blocks and their edges; a loop = a strongly connected component of the control-flow graph (block layout in the
+        # text says nothing: the compiler moves loop latches out of line)
+        blocks, cur = [], {"label": None, "ins": [], "succ": [], "fall": True}
+        for ln in lines[1:]:
+            m = re.match(r"^(\.LBB\d+_\d+):", ln)
+            if m:
+                blocks.append(cur)
+                cur = {"label": m.group(1), "ins": [], "succ": [], "fall": True}
+                continue
+            if not re.match(r"^\s+[a-z]", ln):
+                continue
+            op = ln.split()[0]
+            cur["ins"].append(op)
+            t = re.match(r"^\s+s_c?branch\S*\s+(\.LBB\d+_\d+)", ln)
+            if t:
+                cur["succ"].append(t.group(1))
+            if op in ("s_branch", "s_endpgm", "s_setpc_b64") or t:
+                cur["fall"] = op not in ("s_branch", "s_endpgm", "s_setpc_b64")
+                blocks.append(cur)
+                cur = {"label": None, "ins": [], "succ": [], "fall": True}
+        blocks.append(cur)
+        index = {b["label"]: i for i, b in enumerate(blocks) if b["label"]}
+        edges = [[index[t] for t in b["succ"] if t in index] + ([i + 1] if b["fall"] and i + 1 < len(blocks) else [])
+                 for i, b in enumerate(blocks)]
+        # Tarjan, iterative
+        n = len(blocks)
+        idx, low, on, st, comps, counter = [-1] * n, [0] * n, [False] * n, [], [], 0
+        for root in range(n):
+            if idx[root] != -1:
+                continue
+            work = [(root, 0)]
+            while work:
+                v, ei = work.pop()
+                if ei == 0:
+                    idx[v] = low[v] = counter; counter += 1; st.append(v); on[v] = True
+                recurse = False
+                for k in range(ei, len(edges[v])):
+                    w = edges[v][k]
+                    if idx[w] == -1:
+                        work.append((v, k + 1)); work.append((w, 0)); recurse = True
+                        break
+                    if on[w]:
+                        low[v] = min(low[v], idx[w])
+                if recurse:
+                    continue
+                if low[v] == idx[v]:
+                    comp = []
+                    while True:
+                        w = st.pop(); on[w] = False; comp.append(w)
+                        if w == v:
+                            break
+                    comps.append(comp)
+                if work:
+                    u = work[-1][0]
+                    low[u] = min(low[u], low[v])
+        kernels += 1
+        found = 0
+        for comp in comps:
+            if len(comp) == 1 and comp[0] not in edges[comp[0]]:
+                continue
+            body = [op for bi in comp for op in blocks[bi]["ins"]]
+            if any(x.startswith("v_mfma") for x in body):
+                found += 1
+                assert not any(x.startswith("scratch_") for x in body), f"{name}: scratch access inside an MFMA loop"
+        assert found >= 1, f"{name}: no MFMA loop found"
+        loops += found
+    assert kernels == 72 and loops >= kernels, (kernels, loops)      # 2 widths x 3 shapes x 2 dropout x 3 stage modes, fwd + bwd
