@@ -210,7 +210,7 @@ def test_pingpong_kernels_hold_their_state_in_registers():
     assert seen == 3 + 3 + 1
 
 
-def test_chain_kernels_keep_scratch_out_of_their_chunk_loops():
+def test_chain_kernels_keep_scratch_out_of_their_chunk_loops_and_pad_their_inline_asm():
     """The one-launch layer kernels (ffn_chain.hip) stream their weights through an LDS ring behind COUNTED `s_waitcnt vmcnt(N)`:
     a register reloaded from scratch inside a chunk loop is a vector-memory load the counts do not know, and the compiler waits
     `vmcnt(0)` for it -- the ring drains every iteration (it happened twice while these kernels were written; spills OUTSIDE
@@ -224,6 +224,21 @@ def test_chain_kernels_keep_scratch_out_of_their_chunk_loops():
                            "-S", "--cuda-device-only", os.path.join(csrc, "ffn_chain.hip"), "-o", out], stderr=subprocess.DEVNULL)
     text = open(out).read()
     os.unlink(out)
+    # Inline-asm memory instructions that take their base address in scalar registers start with `s_nop 4`: the compiler restores a
+    # spilled scalar with v_readlane_b32 right in front of the asm, and a vector-memory instruction reading an SGPR written by a
+    # VALU instruction needs five wait states the hazard recogniser does not insert in front of inline asm (two GPU faults).
+    alines = text.split("\n")
+    nasm = 0
+    for i, ln in enumerate(alines):
+        if "ASMSTART" in ln:
+            blk = []
+            j = i + 1
+            while "ASMEND" not in alines[j]:
+                blk.append(alines[j].strip()); j += 1
+            if any(re.search(r"^global_\S+.*\bs\[\d+:\d+\]", x) for x in blk):
+                nasm += 1
+                assert blk[0] == "s_nop 4", blk
+    assert nasm > 100, nasm
     kernels = loops = 0
     for fn in re.split(r"\n(?=_ZN\S*ffn_chain_(?:fwd|bwd)_kernel\S*:)", text)[1:]:
         name = fn.split(":", 1)[0]

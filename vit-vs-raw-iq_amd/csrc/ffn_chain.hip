@@ -89,6 +89,13 @@ __device__ __forceinline__ void lds_read128(bf16x8& dst, uint32_t addr) {
     __builtin_amdgcn_sched_barrier(0);                   \
   } while (0)
 
+// FC_SGPR_HAZARD: the inline-asm memory instructions below take a wave-uniform base address in scalar registers ("s" operand).
+// When the compiler has spilled that value to a VGPR lane it restores it with v_readlane_b32 right in front of the asm -- and a
+// vector-memory instruction that reads an SGPR written by a VALU instruction needs five wait states (gfx9 data hazard), which the
+// hazard recogniser inserts for its own instructions but not in front of inline asm: the access then used a stale address (two
+// memory-access faults on the GPU, both in instances with dozens of spilled scalar registers; found in the ISA as
+// `v_readlane_b32 s4, v255, 36` / `s5` directly followed by the asm's `global_load_dword v222, v148, s[4:5]`).  Every such asm
+// starts with `s_nop 4`; tests/test_host_cpu.py checks that in the compiled ISA.
 // hidden-unit / column offset (in units of 8) of lane group g inside a 32-wide k-step: {0, 16, 8, 24} / 8
 __device__ __forceinline__ int fc_kperm(int g) { return ((g & 1) << 1) | (g >> 1); }
 
@@ -916,7 +923,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
   uint32_t gnext;
   auto load_gate = [&](int c) {
     const uint32_t* src = gate_wave + c * 64;           // wave-uniform
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(gnext) : "v"(lane4), "s"(src) : "memory");
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(gnext) : "v"(lane4), "s"(src) : "memory");          // (s_nop: FC_SGPR_HAZARD)
   };
   const uint32_t gh_lane = (uint32_t)((c16 * F + (odd ? 16 + 4 * (g - 1) : 4 * g)) * 2);      // row c16, this lane's 8 units of a pair
   const IqRng rng = DROP ? rng_resolve(p.rng) : p.rng;
@@ -1081,8 +1088,8 @@ __global__ __launch_bounds__(NW * 64, 2) void ffn_chain_bwd_kernel(const FfnChai
     for (int rg = 0; rg < RG; ++rg) {
       const bf16* base = p.gH + (row0 + rg * 16) * F + f0;          // wave-uniform
       if (row0 + rg * 16 + c16 < p.M) {
-        asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(gh_lane), "v"(hf[rg][0]), "s"(base) : "memory");
-        asm volatile("global_store_dwordx4 %0, %1, %2 offset:64" :: "v"(gh_lane), "v"(hf[rg][1]), "s"(base) : "memory");
+        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\tglobal_store_dwordx4 %0, %3, %2 offset:64"
+                     :: "v"(gh_lane), "v"(hf[rg][0]), "s"(base), "v"(hf[rg][1]) : "memory");          // (s_nop: FC_SGPR_HAZARD; 2 stores)
       }
     }
     // ---- second product: acc2 += gH_c x W1t rows (model columns) 16 j .. +15, hidden units f0 .. f0 + 63 --------------------------
