@@ -449,7 +449,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the raw-IQ (cfg C) measurement beside cfg B")
     ap.add_argument("--prof-steps", type=int, default=5)
-    ap.add_argument("--cpu-budget", type=float, default=40.0, help="seconds of CPU-oracle work per configuration (1 warm-up + 3 timed steps)")
+    ap.add_argument("--cpu-budget", type=float, default=80.0, help="seconds of CPU-oracle work per configuration (1 warm-up + 3 timed steps)")
     ap.add_argument("--no-accuracy", action="store_true", help="skip the accuracy reproduction (cfg A ViT + raw-IQ test geometry, GPU vs CPU oracle)")
     ap.add_argument("--drop", type=float, default=-1.0, help="override the config's dropout probability (diagnostics)")
     a = ap.parse_args()
