@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libiqvit.so")
+LIB_PATH = os.environ.get("IQ_LIBIQVIT") or os.path.join(_HERE, "libiqvit.so")      # (override: A/B runs of two builds on one box)
 
 STATUS = {0: "ok", 1: "invalid argument", 2: "unsupported shape/configuration", 3: "HIP launch error"}
 
