@@ -395,19 +395,37 @@ __global__ __launch_bounds__(256) void head_bwd_w2_kernel(const float* __restric
                                                           int accumulate) {
   __shared__ float sT[8][KMAX][33];
   __shared__ float sS[8][KMAX];
+  __shared__ float sdl[64][KMAX];                       // dlogits of 64 frames at a time, zero-padded to KMAX classes
   const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int d = blockIdx.x * 32 + ol;
   const bool live = d < D;
   float T[KMAX], sd[KMAX];
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) { T[k] = 0.f; sd[k] = 0.f; }
-  for (int b = sl; b < B; b += 8) {
-    const float f = live ? feat_hat[(long)b * D + d] : 0.f;
+  // (K dependent broadcast loads per frame straight from memory made this a 26 us launch for 256 frames on 6 blocks: the rows go
+  //  through LDS 64 frames at a time, all their loads in flight together; the summation order per thread is unchanged)
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * KMAX; i += 256) {
+      const int bb = i / KMAX, k = i - bb * KMAX;
+      sdl[bb][k] = (b0 + bb < B && k < K) ? dlogits[(long)(b0 + bb) * K + k] : 0.f;
+    }
+    __syncthreads();
+    float fv[8];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      const float dl = k < K ? dlogits[(long)b * K + k] : 0.f;      // one address per wave-instruction: a broadcast load
-      T[k] += dl * f;
-      sd[k] += dl;
+    for (int i = 0; i < 8; ++i) {                       // this slice's 8 frames of the group: all loads in flight together
+      const int bb = sl + 8 * i;
+      fv[i] = (live && b0 + bb < B) ? feat_hat[(long)(b0 + bb) * D + d] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int bb = sl + 8 * i;                        // (rows past B hold zeros in sdl)
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        const float dl = sdl[bb][k];
+        T[k] += dl * fv[i];
+        sd[k] += dl;
+      }
     }
   }
 #pragma unroll
